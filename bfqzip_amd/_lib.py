@@ -1,0 +1,97 @@
+"""ctypes loader for libbfqhip.so (the HIP kernels + C-ABI of include/bfqzip_hip.h).
+
+There is no CPU fallback: if the library is missing it is built (hipcc), and
+if it cannot be loaded or no GPU is present the caller gets an exception.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libbfqhip.so")
+_LIB = None
+
+SYMBOLS = [
+    "bfq_default_params", "bfq_create", "bfq_create_error", "bfq_destroy", "bfq_set_params",
+    "bfq_last_error", "bfq_stream", "bfq_device_count", "bfq_build_ebwt", "bfq_count_reads",
+    "bfq_smooth_invert", "bfq_run_reads", "bfq_run_reads_device", "bfq_fetch_ebwt",
+    "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device",
+    "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
+    "bfq_workspace_bytes", "bfq_version",
+]
+
+
+class Params(C.Structure):
+    _fields_ = [(k, C.c_int32) for k in ("K", "m", "v", "f", "t", "term", "M", "B", "ext")] + \
+               [("reserved", C.c_int32 * 7)]
+
+
+class Stats(C.Structure):
+    _fields_ = [(k, C.c_uint64) for k in (
+        "num_clust", "num_clust_discarded", "num_clust_amb_discarded", "num_clust_mod",
+        "num_clust_alleq", "bases_inside", "qs_smoothed", "modified",
+        "n_rows", "n_reads", "n_segments", "n_big_segments")]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+class Synth(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("N", C.c_uint64), ("Lmin", C.c_uint32), ("Lmax", C.c_uint32),
+                ("coverage", C.c_uint32), ("err_ppm", C.c_uint32), ("n_ppm", C.c_uint32),
+                ("snp_every", C.c_uint32), ("dsnp_every", C.c_uint32), ("both_strands", C.c_uint32),
+                ("reserved", C.c_uint32 * 5)]
+
+
+def build(clean=False):
+    """Compile libbfqhip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    d = os.path.join(_HERE, "csrc")
+    if clean:
+        subprocess.check_call(["make", "-s", "-C", d, "clean"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", d, "all"])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        # torch bundles its own HIP/HSA runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).
+        # Two HIP runtimes in one process cannot both own the GPU, so when torch is installed it
+        # is imported first and libbfqhip.so binds to the runtime torch already loaded.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.bfq_create.restype = C.c_void_p
+        L.bfq_create.argtypes = [C.c_int, C.POINTER(Params)]
+        L.bfq_create_error.restype = C.c_char_p
+        L.bfq_destroy.argtypes = [C.c_void_p]
+        L.bfq_set_params.argtypes = [C.c_void_p, C.POINTER(Params)]
+        L.bfq_last_error.restype = C.c_char_p
+        L.bfq_last_error.argtypes = [C.c_void_p]
+        L.bfq_stream.restype = C.c_void_p
+        L.bfq_stream.argtypes = [C.c_void_p]
+        L.bfq_version.restype = C.c_char_p
+        L.bfq_workspace_bytes.restype = C.c_uint64
+        L.bfq_workspace_bytes.argtypes = [C.c_void_p]
+        L.bfq_synth_total.restype = C.c_uint64
+        vp, u64 = C.c_void_p, C.c_uint64
+        L.bfq_build_ebwt.argtypes = [vp, vp, vp, vp, u64, C.c_int, vp, vp, vp]
+        L.bfq_count_reads.argtypes = [vp, u64, C.c_int, C.POINTER(u64)]
+        L.bfq_smooth_invert.argtypes = [vp, vp, vp, vp, C.c_int, u64, vp, vp, vp, C.POINTER(Stats)]
+        L.bfq_run_reads.argtypes = [vp, vp, vp, vp, u64, vp, vp, C.POINTER(Stats)]
+        L.bfq_run_reads_device.argtypes = [vp, vp, vp, vp, u64, u64, vp, vp, C.POINTER(Stats)]
+        L.bfq_fetch_ebwt.argtypes = [vp, vp, vp, vp]
+        L.bfq_synth_default.argtypes = [C.POINTER(Synth), u64, C.c_uint32]
+        L.bfq_synth_total.argtypes = [C.POINTER(Synth)]
+        L.bfq_synth_host.argtypes = [C.POINTER(Synth), vp, vp, vp]
+        L.bfq_synth_device.argtypes = [vp, C.POINTER(Synth), vp, vp, vp]
+        L.bfq_prof_enable.argtypes = [vp, C.c_int]
+        L.bfq_prof_reset.argtypes = [vp]
+        L.bfq_prof_count.argtypes = [vp]
+        L.bfq_prof_get.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double),
+                                   C.POINTER(u64), C.POINTER(C.c_double)]
+        _LIB = L
+    return _LIB

@@ -1,0 +1,157 @@
+"""Host-side mirror of the reference's interface for the hot path.
+
+The reference exposes this path only as executables driven by BFQzip.py /
+BFQzip_ext.py (gsufsort|eGap -> bfq_int|bfq_ext).  `Engine` offers the same
+operations as functions over numpy arrays, all executed by libbfqhip.so on the
+GPU (no CPU fallback):
+
+    build_ebwt(...)     ~ gsufsort <fq> --bwt --qs -o OUT        (BFQzip.py:184)
+                        ~ eGap <fq> --qs --lcp --lbytes 1 -o OUT  (BFQzip_ext.py:177)
+    smooth_invert(...)  ~ bfq_int -e OUT.bwt -q OUT.bwt.qs -o OUT.fq -m 5 ...   (BFQzip.py:215-222)
+                        ~ bfq_ext ... -a OUT.1.lcp                (BFQzip_ext.py:208-214)
+    run_reads(...)      = both, fused, nothing written in between
+
+Parameter names and defaults are those of bfq_int's getopt flags
+(bfq_int.cpp:883-935) plus the compile-time knobs M and B.
+"""
+import ctypes as C
+import numpy as np
+from . import _lib
+
+
+class BfqError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libbfqhip error {code}: {msg}")
+        self.code = code
+
+
+def make_params(k=16, m=2, v=ord(">"), f=40, t=20, s=ord("#"), M=2, B=0, ext=0):
+    p = _lib.Params()
+    p.K, p.m, p.v, p.f, p.t, p.term, p.M, p.B, p.ext = k, m, v, f, t, s, M, B, ext
+    return p
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class Engine:
+    """One GPU context (one stream, one device workspace). Not thread-safe."""
+
+    def __init__(self, device=0, **params):
+        self.L = _lib.lib()
+        self.params = make_params(**params)
+        self.h = self.L.bfq_create(device, C.byref(self.params))
+        if not self.h:
+            raise BfqError(-2, self.L.bfq_create_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.bfq_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def set_params(self, **params):
+        self.params = make_params(**params)
+        self._ck(self.L.bfq_set_params(self.h, C.byref(self.params)))
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise BfqError(rc, self.L.bfq_last_error(self.h).decode())
+
+    # ---- step 1
+    def build_ebwt(self, bases, quals, roff, term_out=ord("#")):
+        bases = np.ascontiguousarray(bases, np.uint8); quals = np.ascontiguousarray(quals, np.uint8)
+        roff = np.ascontiguousarray(roff, np.uint64)
+        N = len(roff) - 1
+        n = int(roff[-1]) + N
+        bwt = np.empty(n, np.uint8); qs = np.empty(n, np.uint8); lcp = np.empty(n, np.uint16)
+        self._ck(self.L.bfq_build_ebwt(self.h, _ptr(bases), _ptr(quals), _ptr(roff), N, term_out,
+                                       _ptr(bwt), _ptr(qs), _ptr(lcp)))
+        return bwt, qs, lcp
+
+    # ---- steps 2-4
+    def smooth_invert(self, bwt, qs, lcp=None):
+        bwt = np.ascontiguousarray(bwt, np.uint8); qs = np.ascontiguousarray(qs, np.uint8)
+        n = len(bwt)
+        N = C.c_uint64(0)
+        self.L.bfq_count_reads(_ptr(bwt), n, self.params.term & 0xFF, C.byref(N))
+        N = N.value
+        lcp_bytes = 0
+        if lcp is not None:
+            lcp = np.ascontiguousarray(lcp)
+            lcp_bytes = lcp.dtype.itemsize
+        ob = np.empty(max(n - N, 1), np.uint8); oq = np.empty(max(n - N, 1), np.uint8)
+        oroff = np.empty(N + 1, np.uint64)
+        st = _lib.Stats()
+        self._ck(self.L.bfq_smooth_invert(self.h, _ptr(bwt), _ptr(qs), _ptr(lcp), lcp_bytes, n,
+                                          _ptr(ob), _ptr(oq), _ptr(oroff), C.byref(st)))
+        return ob[:n - N], oq[:n - N], oroff, st.as_dict()
+
+    # ---- fused
+    def run_reads(self, bases, quals, roff):
+        bases = np.ascontiguousarray(bases, np.uint8); quals = np.ascontiguousarray(quals, np.uint8)
+        roff = np.ascontiguousarray(roff, np.uint64)
+        N = len(roff) - 1
+        ob = np.empty(max(len(bases), 1), np.uint8); oq = np.empty(max(len(bases), 1), np.uint8)
+        st = _lib.Stats()
+        self._ck(self.L.bfq_run_reads(self.h, _ptr(bases), _ptr(quals), _ptr(roff), N, _ptr(ob), _ptr(oq),
+                                      C.byref(st)))
+        return ob[:len(bases)], oq[:len(bases)], st.as_dict()
+
+    def run_reads_device(self, d_bases, d_quals, d_roff, N, total, d_out_bases, d_out_quals):
+        """All arguments are raw device pointers (ints), e.g. torch tensor .data_ptr()."""
+        st = _lib.Stats()
+        self._ck(self.L.bfq_run_reads_device(self.h, d_bases, d_quals, d_roff, N, total, d_out_bases,
+                                             d_out_quals, C.byref(st)))
+        return st.as_dict()
+
+    def fetch_ebwt(self, n):
+        bwt = np.empty(n, np.uint8); qs = np.empty(n, np.uint8); lcp = np.empty(n, np.uint16)
+        self._ck(self.L.bfq_fetch_ebwt(self.h, _ptr(bwt), _ptr(qs), _ptr(lcp)))
+        return bwt, qs, lcp
+
+    # ---- synthetic reads
+    def synth_device(self, spec, d_bases, d_quals, d_roff):
+        self._ck(self.L.bfq_synth_device(self.h, C.byref(spec), d_bases, d_quals, d_roff))
+
+    # ---- profiling
+    def prof_reset(self):
+        self.L.bfq_prof_reset(self.h)
+
+    def prof(self):
+        out = {}
+        name = C.create_string_buffer(64)
+        for i in range(self.L.bfq_prof_count(self.h)):
+            ms = C.c_double(); ln = C.c_uint64(); by = C.c_double()
+            self.L.bfq_prof_get(self.h, i, name, 64, C.byref(ms), C.byref(ln), C.byref(by))
+            if ln.value:
+                out[name.value.decode()] = {"ms": ms.value, "launches": ln.value, "alg_bytes": by.value}
+        return out
+
+    def workspace_bytes(self):
+        return int(self.L.bfq_workspace_bytes(self.h))
+
+
+def synth_spec(N, L, Lmax=None, seed=20240807, **kw):
+    s = _lib.Synth()
+    _lib.lib().bfq_synth_default(C.byref(s), N, L)
+    s.seed = seed
+    if Lmax is not None:
+        s.Lmax = Lmax
+    for k, v in kw.items():
+        setattr(s, k, v)
+    return s
+
+
+def synth_host(spec):
+    """Generate the synthetic reads on the host (same bytes as the device generator)."""
+    L = _lib.lib()
+    total = int(L.bfq_synth_total(C.byref(spec)))
+    bases = np.empty(max(total, 1), np.uint8); quals = np.empty(max(total, 1), np.uint8)
+    roff = np.empty(spec.N + 1, np.uint64)
+    rc = L.bfq_synth_host(C.byref(spec), _ptr(bases), _ptr(quals), _ptr(roff))
+    if rc:
+        raise BfqError(rc, "bfq_synth_host")
+    return bases[:total], quals[:total], roff

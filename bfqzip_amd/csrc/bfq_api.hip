@@ -1,0 +1,498 @@
+// bfq_api.hip -- C-ABI of libbfqhip.so (include/bfqzip_hip.h) and the host-side
+// orchestration of the hot path on one GPU:
+//   step 1  reads -> packed text -> (key,payload) pairs -> LSD radix sort -> tie
+//           refinement (+LCP) -> eBWT / permuted qualities
+//   step 2-3 rank structure -> LCP flags -> clusters (smoothing, replacements)
+//   step 4  LF inversion -> reads
+// Everything runs on the context's stream inside one device workspace.
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+#include <new>
+#include "bfq_internal.h"
+#include "bfq_synth.h"
+
+const char *const BFQ_KERNEL_NAMES[K_NUM] = {
+    "k_text_from_reads", "k_pack3", "k_build_keys", "k_radix_hist", "k_scan", "k_radix_scatter", "k_seg_flags",
+    "k_seg_compact", "k_refine_wave", "k_refine_big", "k_emit_bwt", "k_rank_build", "k_rank_final", "k_lcp_flags",
+    "k_cluster", "k_invert_count", "k_invert", "k_synth", "misc"};
+
+static thread_local std::string g_createErr;
+
+// ---------------------------------------------------------------- context plumbing
+void bfq_ctx::reserve(size_t bytes)
+{
+    bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
+    if (bytes > wsCap) {
+        if (ws) { HIP_CHECK(hipStreamSynchronize(stream)); HIP_CHECK(hipFree(ws)); ws = nullptr; wsCap = 0; }
+        hipError_t e = hipMalloc((void **)&ws, bytes);
+        if (e != hipSuccess) {
+            ws = nullptr;
+            char b[160];
+            snprintf(b, sizeof b, "device workspace of %zu bytes: %s", bytes, hipGetErrorString(e));
+            (void)hipGetLastError();
+            throw BfqError{BFQ_E_NOMEM, b};
+        }
+        wsCap = bytes;
+    }
+    wsTop = 0;
+    d_bwt = d_qual = nullptr; d_lcp = nullptr; n = N = 0;
+}
+void *bfq_ctx::allocBytes(size_t bytes)
+{
+    size_t a = (wsTop + 255) & ~(size_t)255;
+    if (a + bytes > wsCap) {
+        char b[160];
+        snprintf(b, sizeof b, "workspace exhausted: need %zu more bytes at %zu of %zu", bytes, a, wsCap);
+        throw BfqError{BFQ_E_NOMEM, b};
+    }
+    wsTop = a + bytes;
+    return ws + a;
+}
+void bfq_ctx::profBegin(int id, double bytes)
+{
+    if (!profOn) return;
+    if (evUsed + 2 > evPool.size()) {
+        size_t old = evPool.size();
+        evPool.resize(old + 256);
+        for (size_t i = old; i < evPool.size(); i++) HIP_CHECK(hipEventCreate(&evPool[i]));
+    }
+    ProfRec r{id, evPool[evUsed], evPool[evUsed + 1], bytes};
+    evUsed += 2;
+    HIP_CHECK(hipEventRecord(r.a, stream));
+    recs.push_back(r);
+}
+void bfq_ctx::profEnd()
+{
+    if (!profOn) return;
+    HIP_CHECK(hipEventRecord(recs.back().b, stream));
+}
+void bfq_ctx::profCollect()
+{
+    for (auto &r : recs) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            profMs[r.id] += ms; profLaunches[r.id]++; profBytes[r.id] += r.bytes;
+        }
+    }
+    recs.clear();
+    evUsed = 0;
+}
+void bfq_ctx::sync() { HIP_CHECK(hipStreamSynchronize(stream)); }
+void bfq_ctx::zeroCounters() { HIP_CHECK(hipMemsetAsync(d_cnt, 0, sizeof(DevCounters), stream)); }
+void bfq_ctx::fetchCounters()
+{
+    HIP_CHECK(hipMemcpyAsync(&h_cnt, d_cnt, sizeof(DevCounters), hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+// round(-10*log10(x)) exactly as the host libm evaluates it (bfq_int.cpp:370)
+static int host_q(double x) { return (int)round(-10 * log10(x)); }
+
+extern "C" void bfq_default_params(bfq_params *p)
+{
+    memset(p, 0, sizeof(*p));
+    p->K = 16; p->m = 2; p->v = '>'; p->f = 40; p->t = 20; p->term = '#'; p->M = 2; p->B = 0; p->ext = 0;
+}
+extern "C" const char *bfq_create_error(void) { return g_createErr.c_str(); }
+extern "C" const char *bfq_version(void) { return "bfqzip_amd 0.1 (gfx950)"; }
+extern "C" int bfq_device_count(void)
+{
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return nd;
+}
+
+extern "C" bfq_ctx *bfq_create(int device, const bfq_params *p)
+{
+    bfq_ctx *c = nullptr;
+    try {
+        int nd = 0;
+        if (hipGetDeviceCount(&nd) != hipSuccess || nd == 0)
+            throw BfqError{BFQ_E_HIP, "no HIP device available (libbfqhip.so has no CPU fallback)"};
+        if (device < 0 || device >= nd) throw BfqError{BFQ_E_ARG, "device index out of range"};
+        c = new bfq_ctx();
+        c->device = device;
+        if (p) c->P = *p; else bfq_default_params(&c->P);
+        HIP_CHECK(hipSetDevice(device));
+        HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipMalloc((void **)&c->d_cnt, sizeof(DevCounters)));
+        memset(c->profMs, 0, sizeof c->profMs); memset(c->profLaunches, 0, sizeof c->profLaunches);
+        memset(c->profBytes, 0, sizeof c->profBytes);
+        // tables for M=1, computed with the host libm the reference itself would use
+        double pw[256];
+        for (int q = 0; q < 256; q++) pw[q] = pow(10, -((double)(signed char)q - 33) / 10);
+        c->qthrLo = -170; c->qthrN = 311;
+        std::vector<double> thr(c->qthrN);
+        for (int k = 0; k < c->qthrN; k++) {
+            int q = c->qthrLo + k;
+            double xlo = 1e-30, xhi = 1e30;           // host_q(xlo) > q, host_q(xhi) <= q
+            u64 lo, hi;
+            memcpy(&lo, &xlo, 8); memcpy(&hi, &xhi, 8);
+            while (hi - lo > 1) {
+                u64 mid = lo + (hi - lo) / 2;
+                double xm; memcpy(&xm, &mid, 8);
+                if (host_q(xm) <= q) hi = mid; else lo = mid;
+            }
+            memcpy(&thr[k], &hi, 8);
+        }
+        HIP_CHECK(hipMalloc((void **)&c->d_powtab, sizeof pw));
+        HIP_CHECK(hipMalloc((void **)&c->d_qthr, sizeof(double) * c->qthrN));
+        HIP_CHECK(hipMemcpy(c->d_powtab, pw, sizeof pw, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(c->d_qthr, thr.data(), sizeof(double) * c->qthrN, hipMemcpyHostToDevice));
+        return c;
+    } catch (const BfqError &e) {
+        g_createErr = e.msg;
+    } catch (const std::exception &e) {
+        g_createErr = e.what();
+    }
+    delete c;
+    return nullptr;
+}
+
+extern "C" void bfq_destroy(bfq_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto e : c->evPool) (void)hipEventDestroy(e);
+    if (c->ws) (void)hipFree(c->ws);
+    if (c->d_cnt) (void)hipFree(c->d_cnt);
+    if (c->d_powtab) (void)hipFree(c->d_powtab);
+    if (c->d_qthr) (void)hipFree(c->d_qthr);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int bfq_set_params(bfq_ctx *c, const bfq_params *p)
+{
+    if (!c || !p) return BFQ_E_ARG;
+    c->P = *p;
+    return BFQ_OK;
+}
+extern "C" const char *bfq_last_error(bfq_ctx *c) { return c ? c->err.c_str() : "null context"; }
+extern "C" void *bfq_stream(bfq_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" uint64_t bfq_workspace_bytes(bfq_ctx *c) { return c ? c->wsCap : 0; }
+extern "C" int bfq_prof_enable(bfq_ctx *c, int on) { if (!c) return BFQ_E_ARG; c->profOn = on != 0; return BFQ_OK; }
+extern "C" void bfq_prof_reset(bfq_ctx *c)
+{
+    if (!c) return;
+    memset(c->profMs, 0, sizeof c->profMs); memset(c->profLaunches, 0, sizeof c->profLaunches);
+    memset(c->profBytes, 0, sizeof c->profBytes);
+}
+extern "C" int bfq_prof_count(bfq_ctx *c) { (void)c; return K_NUM; }
+extern "C" int bfq_prof_get(bfq_ctx *c, int idx, char *name, int cap, double *ms, uint64_t *launches, double *bytes)
+{
+    if (!c || idx < 0 || idx >= K_NUM) return BFQ_E_ARG;
+    if (name && cap > 0) { strncpy(name, BFQ_KERNEL_NAMES[idx], cap - 1); name[cap - 1] = 0; }
+    if (ms) *ms = c->profMs[idx];
+    if (launches) *launches = c->profLaunches[idx];
+    if (bytes) *bytes = c->profBytes[idx];
+    return BFQ_OK;
+}
+
+// run `body` with the usual prologue/epilogue; maps exceptions to error codes
+template <class F> static int guarded(bfq_ctx *c, F body)
+{
+    if (!c) return BFQ_E_ARG;
+    try {
+        HIP_CHECK(hipSetDevice(c->device));
+        c->err.clear();
+        body();
+        return BFQ_OK;
+    } catch (const BfqError &e) {
+        c->err = e.msg;
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipGetLastError();
+        c->recs.clear(); c->evUsed = 0;
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        c->err = "host out of memory";
+        return BFQ_E_NOMEM;
+    }
+}
+
+static void check_counters(bfq_ctx *c)
+{
+    const DevCounters &h = c->h_cnt;
+    if (h.errSymbol) throw BfqError{BFQ_E_SYMBOL, "symbol outside {A,C,G,T,N,terminator}"};
+    if (h.errTooLong) throw BfqError{BFQ_E_TOO_LONG, "read longer than BFQ_MAX_READ_LEN"};
+    if (h.errInvert) throw BfqError{BFQ_E_NOT_EBWT, "LF walk did not close: not an eBWT of a read collection"};
+    if (h.mismatch) throw BfqError{BFQ_E_NOT_EBWT, "eBWT is not in #_i<#_j<A<C<G<N<T suffix order"};
+    if (h.errFreq3) throw BfqError{BFQ_E_FREQ3, "three frequent symbols in a cluster (bfq_int.cpp:505 assert); raise -f"};
+}
+static void fill_stats(bfq_ctx *c, bfq_stats *st)
+{
+    if (!st) return;
+    const u64 *s = c->h_cnt.stats;
+    st->num_clust = s[0]; st->num_clust_discarded = s[1]; st->num_clust_amb_discarded = s[2];
+    st->num_clust_mod = s[3]; st->num_clust_alleq = s[4]; st->bases_inside = s[5];
+    st->qs_smoothed = s[6]; st->modified = s[7];
+    st->n_rows = c->n; st->n_reads = c->N;
+}
+
+// workspace bound for a collection of n rows (see DESIGN.md "HBM layout")
+static size_t ws_need(u64 n, u64 N, u64 extra)
+{
+    u64 nb = n / 32768 + 2;
+    size_t need = 0;
+    need += 4 * (n + 256) + 1024;                       // bwt, qual, lcp16
+    need += 8 * (n / 21 + 8);                           // packed text
+    need += 4 * 8 * (n + 256);                          // key/payload ping-pong
+    need += 256 * nb * 12 + (nb + 4096) * 64;           // radix histograms + scan partials
+    need += 16 * (N + 64);                              // offsets / lengths
+    need += extra + (64u << 20);
+    return need;
+}
+
+// ---------------------------------------------------------------- step 1
+void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,
+                      int termOut, bfq_stats *st)
+{
+    u64 n = total + N;
+    if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^40 rows)"};
+    c->n = n; c->N = N;
+    c->d_bwt = c->alloc<u8>(n + 64);
+    c->d_qual = c->alloc<u8>(n + 64);
+    c->d_lcp = c->alloc<u16>(n + 64);
+    if (!n) return;
+    size_t m0 = c->mark();
+    u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
+    u64 *text3 = c->alloc<u64>(nwords);
+    u64 *keysA = c->alloc<u64>(n + 8), *valsA = c->alloc<u64>(n + 8);
+    size_t mB = c->mark();
+    u64 *keysB = c->alloc<u64>(n + 8), *valsB = c->alloc<u64>(n + 8);
+    u8 *T8 = (u8 *)keysB, *Q8 = (u8 *)valsB;           // dead before the sort's first scatter
+    bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
+    bfq_build_keys(c, T8, Q8, text3, n, keysA, valsA);
+    bfq_radix_sort(c, keysA, valsA, keysB, valsB, n);
+    c->release(mB);                                     // segment lists reuse the B buffers
+    bfq_refine(c, keysA, valsA, text3, n, c->d_lcp, st);
+    bfq_emit_bwt(c, valsA, n, termOut, c->d_bwt, c->d_qual);
+    c->release(m0);
+}
+
+// ---------------------------------------------------------------- steps 2-4
+static void steps234_device(bfq_ctx *c, const u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals)
+{
+    u64 n = c->n, N = c->N;
+    if (!n) return;
+    RankIndex R = bfq_rank_build(c, c->d_bwt, n, c->P.term);
+    u8 *in = c->alloc<u8>(n + 64);
+    u8 *modsym = c->alloc<u8>(n + 64);
+    bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
+    bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n, modsym);
+    bfq_invert(c, R, c->d_qual, modsym, N, d_roff, d_out_bases, d_out_quals);
+}
+
+extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_quals,
+                                    const uint64_t *d_read_off, uint64_t N, uint64_t total, uint8_t *d_out_bases,
+                                    uint8_t *d_out_quals, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        if (st) memset(st, 0, sizeof *st);
+        c->reserve(ws_need(total + N, N, 0));
+        c->zeroCounters();
+        bfq_step1_device(c, d_bases, d_quals, (const u64 *)d_read_off, N, total, c->P.term, st);
+        steps234_device(c, (const u64 *)d_read_off, d_out_bases, d_out_quals);
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+        fill_stats(c, st);
+    });
+}
+
+extern "C" int bfq_run_reads(bfq_ctx *c, const uint8_t *h_bases, const uint8_t *h_quals, const uint64_t *h_read_off,
+                             uint64_t N, uint8_t *h_out_bases, uint8_t *h_out_quals, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        if (st) memset(st, 0, sizeof *st);
+        if (!h_read_off) throw BfqError{BFQ_E_ARG, "null read offsets"};
+        u64 total = h_read_off[N];
+        c->reserve(ws_need(total + N, N, 4 * (total + 256) + 8 * (N + 64)));
+        c->zeroCounters();
+        u8 *db = c->alloc<u8>(total + 64), *dq = c->alloc<u8>(total + 64);
+        u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
+        u64 *dr = c->alloc<u64>(N + 1);
+        HIP_CHECK(hipMemcpyAsync(db, h_bases, total, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(dq, h_quals, total, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(dr, h_read_off, 8 * (N + 1), hipMemcpyHostToDevice, c->stream));
+        bfq_step1_device(c, db, dq, dr, N, total, c->P.term, st);
+        steps234_device(c, dr, ob, oq);
+        HIP_CHECK(hipMemcpyAsync(h_out_bases, ob, total, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpyAsync(h_out_quals, oq, total, hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+        fill_stats(c, st);
+    });
+}
+
+extern "C" int bfq_build_ebwt(bfq_ctx *c, const uint8_t *h_bases, const uint8_t *h_quals, const uint64_t *h_read_off,
+                              uint64_t N, int term_out, uint8_t *h_bwt, uint8_t *h_bwtqs, uint16_t *h_lcp16)
+{
+    return guarded(c, [&] {
+        if (!h_read_off) throw BfqError{BFQ_E_ARG, "null read offsets"};
+        u64 total = h_read_off[N], n = total + N;
+        c->reserve(ws_need(n, N, 2 * (total + 256) + 8 * (N + 64)));
+        c->zeroCounters();
+        u8 *db = c->alloc<u8>(total + 64), *dq = c->alloc<u8>(total + 64);
+        u64 *dr = c->alloc<u64>(N + 1);
+        HIP_CHECK(hipMemcpyAsync(db, h_bases, total, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(dq, h_quals, total, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(dr, h_read_off, 8 * (N + 1), hipMemcpyHostToDevice, c->stream));
+        bfq_step1_device(c, db, dq, dr, N, total, term_out, nullptr);
+        if (h_bwt) HIP_CHECK(hipMemcpyAsync(h_bwt, c->d_bwt, n, hipMemcpyDeviceToHost, c->stream));
+        if (h_bwtqs) HIP_CHECK(hipMemcpyAsync(h_bwtqs, c->d_qual, n, hipMemcpyDeviceToHost, c->stream));
+        if (h_lcp16) HIP_CHECK(hipMemcpyAsync(h_lcp16, c->d_lcp, 2 * n, hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+    });
+}
+
+extern "C" int bfq_fetch_ebwt(bfq_ctx *c, uint8_t *h_bwt, uint8_t *h_qs, uint16_t *h_lcp16)
+{
+    return guarded(c, [&] {
+        if (!c->d_bwt) throw BfqError{BFQ_E_ARG, "no eBWT resident"};
+        if (h_bwt) HIP_CHECK(hipMemcpyAsync(h_bwt, c->d_bwt, c->n, hipMemcpyDeviceToHost, c->stream));
+        if (h_qs) HIP_CHECK(hipMemcpyAsync(h_qs, c->d_qual, c->n, hipMemcpyDeviceToHost, c->stream));
+        if (h_lcp16) HIP_CHECK(hipMemcpyAsync(h_lcp16, c->d_lcp, 2 * c->n, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    });
+}
+
+extern "C" int bfq_count_reads(const uint8_t *h_bwt, uint64_t n, int term, uint64_t *N)
+{
+    if (!N || (n && !h_bwt)) return BFQ_E_ARG;
+    u64 k = 0;
+    for (u64 i = 0; i < n; i++) k += (h_bwt[i] == (u8)term);
+    *N = k;
+    return BFQ_OK;
+}
+
+__global__ __launch_bounds__(256) void k_compare_bytes(const u8 *__restrict__ a, const u8 *__restrict__ b, u64 n,
+                                                       DevCounters *cnt)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) atomicAdd(&cnt->mismatch, 1ull);
+}
+__global__ __launch_bounds__(256) void k_widen_lens(const u32 *__restrict__ lens, u64 N, u64 *__restrict__ out)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) out[i] = lens[i];
+}
+
+extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp,
+                                 int lcp_bytes, uint64_t n, uint8_t *h_out_bases, uint8_t *h_out_quals,
+                                 uint64_t *h_out_read_off, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        if (st) memset(st, 0, sizeof *st);
+        if (n && (!h_bwt || !h_bwtqs)) throw BfqError{BFQ_E_ARG, "null eBWT"};
+        if (h_lcp && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
+        uint64_t Nr = 0;
+        bfq_count_reads(h_bwt, n, c->P.term & 0xFF, &Nr);
+        u64 N = Nr;
+        if (n && N == 0) throw BfqError{BFQ_E_NOT_EBWT, "no terminator in the eBWT"};
+        u64 total = n - N;
+        c->reserve(ws_need(n, N, 6 * (n + 256) + 16 * (N + 64)));
+        c->zeroCounters();
+        u8 *in_bwt = c->alloc<u8>(n + 64), *in_qs = c->alloc<u8>(n + 64);
+        u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
+        u64 *d_roff = c->alloc<u64>(N + 1);
+        u32 *lens = c->alloc<u32>(N + 1);
+        HIP_CHECK(hipMemcpyAsync(in_bwt, h_bwt, n, hipMemcpyHostToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(in_qs, h_bwtqs, n, hipMemcpyHostToDevice, c->stream));
+        std::vector<u16> lcp16;
+        if (h_lcp) {
+            // explicit LCP (bfq_ext): persistent arrays hold the given eBWT directly
+            c->n = n; c->N = N;
+            c->d_bwt = in_bwt; c->d_qual = in_qs;
+            c->d_lcp = c->alloc<u16>(n + 64);
+            lcp16.resize(n);
+            for (u64 i = 0; i < n; i++) {
+                u64 v = lcp_bytes == 1 ? ((const u8 *)h_lcp)[i] : lcp_bytes == 2 ? ((const u16 *)h_lcp)[i] : ((const u32 *)h_lcp)[i];
+                lcp16[i] = (u16)(v > 0xFFFE ? 0xFFFE : v);
+            }
+            HIP_CHECK(hipMemcpyAsync(c->d_lcp, lcp16.data(), 2 * n, hipMemcpyHostToDevice, c->stream));
+            size_t m = c->mark();
+            RankIndex R0 = bfq_rank_build(c, in_bwt, n, c->P.term);
+            bfq_invert_count(c, R0, N, lens);
+            bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
+            c->release(m);
+        } else {
+            // bfq_int deduces the LCP from the BWT (bfq_int.cpp:183-300): here by inverting
+            // the eBWT and rebuilding it with step 1, which also yields the LCP array
+            size_t m = c->mark();
+            u8 *rb = c->alloc<u8>(total + 64), *rq = c->alloc<u8>(total + 64);
+            {
+                size_t m2 = c->mark();
+                RankIndex R0 = bfq_rank_build(c, in_bwt, n, c->P.term);
+                bfq_invert_count(c, R0, N, lens);
+                bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
+                u64 tot2 = 0;
+                HIP_CHECK(hipMemcpyAsync(&tot2, d_roff + N, 8, hipMemcpyDeviceToHost, c->stream));
+                c->fetchCounters();
+                check_counters(c);
+                if (tot2 != total) throw BfqError{BFQ_E_NOT_EBWT, "LF walks do not cover the eBWT"};
+                int B = c->P.B; c->P.B = 0;
+                bfq_invert(c, R0, in_qs, nullptr, N, d_roff, rb, rq);
+                c->P.B = B;
+                c->release(m2);
+            }
+            bfq_step1_device(c, rb, rq, d_roff, N, total, c->P.term, st);
+            KLAUNCH(c, K_MISC, 2.0 * (double)n, k_compare_bytes, ceil_div(n ? n : 1, 256), 256, (const u8 *)c->d_bwt,
+                    (const u8 *)in_bwt, n, c->d_cnt);
+            HIP_CHECK(hipMemcpyAsync(c->d_qual, in_qs, n, hipMemcpyDeviceToDevice, c->stream));
+            (void)m;   // rb/rq stay allocated below the step-1 arrays; the arena is reset per call
+        }
+        steps234_device(c, d_roff, ob, oq);
+        if (total) {
+            HIP_CHECK(hipMemcpyAsync(h_out_bases, ob, total, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipMemcpyAsync(h_out_quals, oq, total, hipMemcpyDeviceToHost, c->stream));
+        }
+        HIP_CHECK(hipMemcpyAsync(h_out_read_off, d_roff, 8 * (N + 1), hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+        fill_stats(c, st);
+    });
+}
+
+// ---------------------------------------------------------------- synthetic reads
+extern "C" void bfq_synth_default(bfq_synth *s, uint64_t N, uint32_t L)
+{
+    memset(s, 0, sizeof *s);
+    s->seed = 20240807; s->N = N; s->Lmin = s->Lmax = L; s->coverage = 30;
+    s->err_ppm = 10000; s->n_ppm = 1000; s->snp_every = 1000; s->dsnp_every = 10000; s->both_strands = 1;
+}
+extern "C" uint64_t bfq_synth_total(const bfq_synth *s)
+{
+    if (s->Lmin >= s->Lmax) return s->N * (u64)s->Lmin;
+    u64 t = 0;
+    for (u64 i = 0; i < s->N; i++) t += bfq_synth_len(s, i);
+    return t;
+}
+extern "C" int bfq_synth_host(const bfq_synth *s, uint8_t *h_bases, uint8_t *h_quals, uint64_t *h_read_off)
+{
+    if (!s || !h_read_off) return BFQ_E_ARG;
+    u64 o = 0;
+    for (u64 i = 0; i < s->N; i++) {
+        u32 len = bfq_synth_len(s, i);
+        h_read_off[i] = o;
+        for (u32 k = 0; k < len; k++) bfq_synth_base(s, i, len, k, h_bases + o + k, h_quals + o + k);
+        o += len;
+    }
+    h_read_off[s->N] = o;
+    return BFQ_OK;
+}
+extern "C" int bfq_synth_device(bfq_ctx *c, const bfq_synth *s, uint8_t *d_bases, uint8_t *d_quals, uint64_t *d_read_off)
+{
+    return guarded(c, [&] {
+        if (!s) throw BfqError{BFQ_E_ARG, "null synth spec"};
+        c->reserve(16 * (s->N + 4096) + (64u << 20));
+        bfq_synth_launch(c, s, d_bases, d_quals, (u64 *)d_read_off);
+        c->sync();
+        c->profCollect();
+    });
+}

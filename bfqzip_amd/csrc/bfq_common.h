@@ -1,0 +1,128 @@
+// bfq_common.h -- helpers shared by host and device code (plain C++, no HIP types).
+//
+// Alphabet and order follow the reference's consumers: F array laid out
+// # A C G N T (external/bwt2lcp/dna_bwt_n.hpp:46-61) and read i starting at BWT
+// row i (src_int_mem/bfq_int.cpp:775-778), i.e. #_i < #_j (i<j) < A < C < G < N < T.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define BFQ_HD __host__ __device__ __forceinline__
+#else
+#define BFQ_HD inline
+#endif
+
+typedef unsigned long long u64;
+typedef unsigned int u32;
+typedef unsigned short u16;
+typedef unsigned char u8;
+
+// ---- symbol codes: # 0, A 1, C 2, G 3, N 4, T 5 (order preserving) ----------
+#define BFQ_CODE_INVALID 7
+BFQ_HD u32 bfq_base_code(u8 c)
+{
+    return c == 'A' ? 1u : c == 'C' ? 2u : c == 'G' ? 3u : c == 'N' ? 4u : c == 'T' ? 5u
+                                                                              : (u32)BFQ_CODE_INVALID;
+}
+BFQ_HD u8 bfq_code_sym(u32 code)   // code 0..5 -> ASCII "#ACGNT" (byte LUT in a u64)
+{
+    return (u8)((0x0000544E47434123ull >> (8u * code)) & 0xFFu);
+}
+
+// ---- packed text: 21 symbols of 3 bits per 64-bit word, symbol j of a word in
+// bits [3*(20-j), 3*(20-j)+2]; bit 63 is always 0.  A "key" is the 21-symbol
+// window starting at any text position, with everything from the first
+// terminator on cleared, so that keys compare like the suffixes' first 21
+// symbols and equal keys holding a terminator are identical suffixes.
+#define BFQ_SYMS_PER_WORD 21
+#define BFQ_M63 0x7FFFFFFFFFFFFFFFull
+#define BFQ_LOW3 0x1249249249249249ull   // bit 0 of each of the 21 fields
+
+BFQ_HD int bfq_clz64(u64 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)x);
+#else
+    return x ? __builtin_clzll(x) : 64;
+#endif
+}
+BFQ_HD int bfq_popc64(u64 x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
+
+// mask of the low bit of every zero field of a 63-bit window
+BFQ_HD u64 bfq_zero_fields(u64 k)
+{
+    u64 t = k | (k >> 1) | (k >> 2);
+    return ~t & BFQ_LOW3;
+}
+// clear everything after the first terminator (zero field)
+BFQ_HD u64 bfq_mask_key(u64 k)
+{
+    u64 z = bfq_zero_fields(k);
+    if (z == 0) return k;
+    int b = 63 - bfq_clz64(z);            // low bit of the first zero field (0,3,..,60)
+    return k & ~((1ull << (b + 3)) - 1ull);
+}
+BFQ_HD bool bfq_key_has_term(u64 maskedKey) { return bfq_zero_fields(maskedKey) != 0; }
+// number of symbols before the first terminator (21 if none)
+BFQ_HD int bfq_key_tpos(u64 maskedKey)
+{
+    u64 z = bfq_zero_fields(maskedKey);
+    if (z == 0) return BFQ_SYMS_PER_WORD;
+    int b = 63 - bfq_clz64(z);
+    return (60 - b) / 3;
+}
+// common prefix (in symbols) of two masked windows; terminators never match
+BFQ_HD int bfq_key_lcp(u64 a, u64 b)
+{
+    u64 x = a ^ b;
+    if (x == 0) return bfq_key_tpos(a);
+    return (bfq_clz64(x) - 1) / 3;
+}
+// raw 21-symbol window at text position p (text3 padded with >= 2 zero words)
+BFQ_HD u64 bfq_window(const u64 *text3, u64 p)
+{
+    u64 w = p / BFQ_SYMS_PER_WORD;
+    u32 o = (u32)(p - w * BFQ_SYMS_PER_WORD) * 3u;
+    u64 hi = (text3[w] << o) & BFQ_M63;
+    u64 lo = o ? (text3[w + 1] >> (63u - o)) : 0ull;
+    return hi | lo;
+}
+BFQ_HD u64 bfq_key_at(const u64 *text3, u64 p) { return bfq_mask_key(bfq_window(text3, p)); }
+
+// ---- sort payload: text position + the (symbol, quality) preceding it --------
+#define BFQ_POS_BITS 40
+#define BFQ_POS_MASK ((1ull << BFQ_POS_BITS) - 1ull)
+BFQ_HD u64 bfq_pack_val(u64 pos, u32 prevCode, u32 prevQual)
+{
+    return pos | ((u64)prevCode << 40) | ((u64)prevQual << 48);
+}
+BFQ_HD u64 bfq_val_pos(u64 v) { return v & BFQ_POS_MASK; }
+BFQ_HD u32 bfq_val_code(u64 v) { return (u32)(v >> 40) & 7u; }
+BFQ_HD u32 bfq_val_qual(u64 v) { return (u32)(v >> 48) & 0xFFu; }
+
+// ---- Illumina 8-level binning, ASCII in/out (bfq_int.cpp:307-319) ------------
+BFQ_HD u32 bfq_bin8(u32 asciiQ)
+{
+    int q = (int)(signed char)asciiQ - 33;
+    if (q >= 40) q = 40; else if (q >= 35) q = 37; else if (q >= 30) q = 33;
+    else if (q >= 25) q = 27; else if (q >= 20) q = 22; else if (q >= 10) q = 15;
+    else if (q >= 2) q = 6;
+    return (u32)(q + 33) & 0xFFu;
+}
+
+// ---- counter-based hash for the synthetic generator --------------------------
+BFQ_HD u64 bfq_mix64(u64 x)
+{
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+BFQ_HD u64 bfq_hash2(u64 seed, u64 tag, u64 x) { return bfq_mix64(bfq_mix64(seed ^ (tag * 0xD6E8FEB86659FD93ull)) + x); }

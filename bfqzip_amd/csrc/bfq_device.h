@@ -1,0 +1,78 @@
+// bfq_device.h -- device-only helpers (wave64 / workgroup primitives) for gfx950.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "bfq_common.h"
+
+#define BFQ_WAVE 64
+
+__device__ __forceinline__ u32 bfq_lane() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ u64 bfq_lanemask_lt() { return (1ull << bfq_lane()) - 1ull; }
+
+// 64-bit cross-lane moves built from the 32-bit primitives
+__device__ __forceinline__ u64 bfq_readlane64(u64 v, int srcLane)   // srcLane wave-uniform
+{
+    u32 lo = (u32)__builtin_amdgcn_readlane((int)(u32)v, srcLane);
+    u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), srcLane);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 bfq_bpermute64(u64 v, int srcLane)    // pull from any lane
+{
+    u32 lo = (u32)__builtin_amdgcn_ds_bpermute(srcLane << 2, (int)(u32)v);
+    u32 hi = (u32)__builtin_amdgcn_ds_bpermute(srcLane << 2, (int)(u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 bfq_permute64(u64 v, int dstLane)     // push to a lane (dstLane a permutation)
+{
+    u32 lo = (u32)__builtin_amdgcn_ds_permute(dstLane << 2, (int)(u32)v);
+    u32 hi = (u32)__builtin_amdgcn_ds_permute(dstLane << 2, (int)(u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+
+// inclusive wave scan (sum) of u64 / u32
+__device__ __forceinline__ u64 bfq_wave_incscan64(u64 v)
+{
+    u32 lane = bfq_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u64 t = bfq_bpermute64(v, (int)lane - d);
+        if ((int)lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 bfq_wave_incscan32(u32 v)
+{
+    u32 lane = bfq_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = (u32)__builtin_amdgcn_ds_bpermute(((int)lane - d) << 2, (int)v);
+        if ((int)lane >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive scan over a 256-thread workgroup; sh must hold 4 entries; returns the
+// exclusive prefix, *total = workgroup sum.  Contains two __syncthreads().
+__device__ __forceinline__ u64 bfq_block_exscan64(u64 v, u64 *sh, u64 *total)
+{
+    u32 lane = bfq_lane(), w = threadIdx.x >> 6;
+    u64 inc = bfq_wave_incscan64(v);
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    u64 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+    u64 base = (w > 0 ? s0 : 0) + (w > 1 ? s1 : 0) + (w > 2 ? s2 : 0);
+    *total = s0 + s1 + s2 + s3;
+    __syncthreads();
+    return base + inc - v;
+}
+__device__ __forceinline__ u32 bfq_block_exscan32(u32 v, u32 *sh, u32 *total)
+{
+    u32 lane = bfq_lane(), w = threadIdx.x >> 6;
+    u32 inc = bfq_wave_incscan32(v);
+    if (lane == 63) sh[w] = inc;
+    __syncthreads();
+    u32 s0 = sh[0], s1 = sh[1], s2 = sh[2], s3 = sh[3];
+    u32 base = (w > 0 ? s0 : 0) + (w > 1 ? s1 : 0) + (w > 2 ? s2 : 0);
+    *total = s0 + s1 + s2 + s3;
+    __syncthreads();
+    return base + inc - v;
+}

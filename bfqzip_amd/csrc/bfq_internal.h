@@ -1,0 +1,138 @@
+// bfq_internal.h -- context, workspace arena, profiling and stage entry points
+// shared by the .hip translation units of libbfqhip.so.  Not part of the ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+#include "../../include/bfqzip_hip.h"
+#include "bfq_common.h"
+
+struct BfqError {
+    int code;
+    std::string msg;
+};
+
+#define HIP_CHECK(expr)                                                                        \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess)                                                                 \
+            throw BfqError{BFQ_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e__)};     \
+    } while (0)
+
+// ---- kernel ids for the profiler ------------------------------------------------
+enum BfqKernel {
+    K_TEXT = 0, K_PACK, K_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_SEG_FLAGS, K_SEG_COMPACT,
+    K_REFINE_WAVE, K_REFINE_BIG, K_EMIT, K_RANK_BUILD, K_RANK_FINAL, K_LCP_FLAGS, K_CLUSTER,
+    K_INVERT_COUNT, K_INVERT, K_SYNTH, K_MISC, K_NUM
+};
+extern const char *const BFQ_KERNEL_NAMES[K_NUM];
+
+struct ProfRec { int id; hipEvent_t a, b; double bytes; };
+
+// device-side counters / small outputs read back by the host (one hipMemcpy)
+struct DevCounters {
+    u64 stats[8];        // bfq_stats cluster counters, same order
+    u64 bigCount;        // number of segments > 64 rows
+    u64 errSymbol;       // >0: forbidden symbol met
+    u64 errInvert;       // >0: LF walk did not close
+    u64 errFreq3;        // >0: three frequent symbols in a cluster
+    u64 errTooLong;      // >0: read longer than BFQ_MAX_READ_LEN
+    u64 tot[6];          // symbol totals of the eBWT: # A C G N T
+    u64 mismatch;        // >0: rebuilt eBWT differs from the given one
+    u64 pad[11];
+};
+
+// rank structure over the eBWT: 256 rows per 128-byte block
+//   u64 cnt[4]  : occurrences of A,C,G,T before the block
+//   u64 pl[4][3]: 4 groups of 64 rows, 3 bit planes of the symbol code
+struct RankBlock { u64 cnt[4]; u64 pl[4][3]; };
+
+struct RankIndex {
+    const RankBlock *blk;   // [nblk]
+    const u64 *cntN;        // [nblk] occurrences of N before the block
+    const u64 *F;           // device: F[6] in order # A C G N T (dna_bwt_n.hpp:46-61)
+    u64 n;
+};
+
+struct bfq_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bfq_params P;
+    std::string err;
+
+    // workspace arena (bump allocator, reset per top-level call)
+    char *ws = nullptr;
+    size_t wsCap = 0, wsTop = 0;
+    void reserve(size_t bytes);
+    void *allocBytes(size_t bytes);
+    template <class T> T *alloc(size_t count) { return (T *)allocBytes(count * sizeof(T)); }
+    size_t mark() const { return wsTop; }
+    void release(size_t m) { wsTop = m; }
+
+    DevCounters *d_cnt = nullptr;   // device
+    DevCounters h_cnt;              // host copy
+    double *d_powtab = nullptr;     // 256 doubles: pow(10,-(q-33)/10) by host libm
+    double *d_qthr = nullptr;       // thresholds for round(-10*log10(x))
+    int qthrLo = 0, qthrN = 0;
+
+    // last eBWT (device, inside ws)
+    u8 *d_bwt = nullptr; u8 *d_qual = nullptr; u16 *d_lcp = nullptr;
+    u64 n = 0, N = 0;
+
+    // profiling
+    bool profOn = true;
+    std::vector<hipEvent_t> evPool;
+    size_t evUsed = 0;
+    std::vector<ProfRec> recs;
+    double profMs[K_NUM];
+    u64 profLaunches[K_NUM];
+    double profBytes[K_NUM];
+    void profBegin(int id, double bytes);
+    void profEnd();
+    void profCollect();   // after a stream synchronise
+
+    void sync();
+    void fetchCounters();
+    void zeroCounters();
+};
+
+#define KLAUNCH(ctx, kid, bytes, kernel, grid, block, ...)                                     \
+    do {                                                                                       \
+        (ctx)->profBegin((kid), (double)(bytes));                                              \
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), 0, (ctx)->stream, __VA_ARGS__);    \
+        (ctx)->profEnd();                                                                      \
+        HIP_CHECK(hipGetLastError());                                                          \
+    } while (0)
+
+static inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
+
+// ---- stage entry points (each in its own .hip file) --------------------------------
+// scan: out[i] = sum(in[0..i)) ; T in {u8,u32,u64}; total (device u64) optional
+void bfq_exscan_u8(bfq_ctx *c, const u8 *in, u64 *out, u64 n, u64 *d_total);
+void bfq_exscan_u32(bfq_ctx *c, const u32 *in, u64 *out, u64 n, u64 *d_total);
+void bfq_exscan_u64(bfq_ctx *c, const u64 *in, u64 *out, u64 n, u64 *d_total);
+
+// step 1 pieces
+void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 n,
+                    u8 *T8, u8 *Q8, u64 *text3, u64 nwords);
+void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u64 *keys, u64 *vals);
+// LSD radix sort of (key,val) pairs on key bits [0,63); result ends in keysA/valsA
+void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, u64 n);
+// tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
+void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
+void bfq_emit_bwt(bfq_ctx *c, const u64 *vals, u64 n, int termOut, u8 *bwt, u8 *qs);
+// whole step 1 on device-resident reads; leaves c->d_bwt/d_qual/d_lcp
+void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,
+                      int termOut, bfq_stats *st);
+
+// steps 2-4 pieces
+RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, u64 n, int term);
+void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in);
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, u8 *qual, const u8 *in, u64 n, u8 *modsym);
+// LF walks: lengths only, then emission at given offsets
+void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);
+void bfq_invert(bfq_ctx *c, const RankIndex &R, const u8 *qual, const u8 *modsym, u64 N, const u64 *d_roff,
+                u8 *out_bases, u8 *out_quals);
+
+void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, u64 *d_roff);

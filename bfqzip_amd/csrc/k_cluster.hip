@@ -1,0 +1,207 @@
+// k_cluster.hip -- LCP flags, positional clusters, noise reduction and quality smoothing.
+//
+//   k_lcp_flags : in(r) = thr(r) && !min(r), the only thing the cluster scan of
+//                 bfq_int.cpp:685-711 looks at; thr/min in the closed form that the
+//                 suffix-tree navigation of bfq_int.cpp:139-181,183-300 produces and
+//                 that bfq_ext.cpp:377-392 streams from the LCP file:
+//                   thr[r] = r>=1 && LCP[r]>=K
+//                   min[r] = 1<=r<=n-2 && LCP[r-1]>LCP[r] && LCP[r+1]>=LCP[r]
+//   k_cluster   : every maximal run [b,e] of in() is the cluster [b-1,e]
+//                 (process_cluster(begin,i), bfq_int.cpp:414-626, border=1); clusters
+//                 are disjoint, so each one is handled independently by the thread
+//                 that sits on its first in() row, walking it in row order exactly as
+//                 the reference does (the M=1 double sum keeps its order).
+// Base replacements are recorded in modsym[r] (0 = untouched) instead of the
+// reference's rankbv bit + BWT_MOD string (bfq_int.cpp:386-387,582-591).
+#include <stdlib.h>
+#include "bfq_internal.h"
+#include "bfq_device.h"
+#include "bfq_rank.h"
+
+__global__ __launch_bounds__(256) void k_lcp_flags(const u16 *__restrict__ lcp, u64 n, int K, u8 *__restrict__ in)
+{
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int l = (int)lcp[r];
+    bool thr = (r >= 1) && (l >= K);
+    bool mn = false;
+    if (r >= 1 && r + 2 <= n) mn = ((int)lcp[r - 1] > l) && ((int)lcp[r + 1] >= l);
+    in[r] = (thr && !mn) ? 1 : 0;
+}
+
+struct ClStat { u32 clust, disc, amb, mod, alleq, bases, qs, modb; };
+
+struct ClusterArgs {
+    RankIndex R;
+    const u8 *bwt; u8 *qual; const u8 *in; u8 *modsym; u64 n;
+    int m, v, f, t, term, M, ext;
+    const double *powtab;   // [256] pow(10,-((signed char)q-33)/10), host libm
+    const double *qthr;     // [qthrN] decreasing: smallest x with round(-10*log10(x)) <= qthrLo+k
+    int qthrLo, qthrN;
+    DevCounters *cnt;
+};
+
+__device__ __forceinline__ int ord5(u8 c)   // bfq_int.cpp:106-110: A0 C1 G2 T3 N4
+{
+    return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : 4;
+}
+__device__ __forceinline__ u8 dna5(int i) { return (u8)((0x4E54474341ull >> (8 * i)) & 0xFF); }   // "ACGTN"
+
+// bfq_int.cpp:376-405 modBasesSmoothQS
+__device__ __forceinline__ void mod_smooth(const ClusterArgs &a, u64 start, u64 end, u8 newSymb, int newqs, u32 lowQS, ClStat &st)
+{
+    const u8 TERM = (u8)a.term;
+    for (u64 j = start; j <= end; j++) {
+        u8 b = a.bwt[j];
+        if (b == TERM) continue;
+        if (b != newSymb && !((lowQS >> ord5(b)) & 1u)) { a.modsym[j] = newSymb; st.modb++; }
+        else if (b == newSymb) { a.qual[j] = (u8)newqs; st.qs++; }
+        else if (newqs < (int)(signed char)a.qual[j]) { a.qual[j] = (u8)newqs; st.qs++; }
+    }
+}
+
+__device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 start, u64 end, ClStat &st)
+{
+    const u8 TERM = (u8)a.term;
+    u64 size = end - start + 1;
+    if (size < (u64)(long long)a.m) return;                                   // :422
+    u32 freqs[5] = {0, 0, 0, 0, 0};
+    u32 lowQS = 0;
+    u64 base_num = 0;
+    for (u64 j = start; j <= end; j++) {                                       // :437-449
+        u8 b = a.bwt[j];
+        if (b != TERM) {
+            int o = ord5(b);
+            freqs[o]++; base_num++;
+            if ((int)(signed char)a.qual[j] >= a.t + 33) lowQS |= 1u << o;
+        }
+    }
+    st.clust++;
+    if (base_num == 0) return;                                                 // :453
+    st.bases += (u32)base_num;
+
+    int newqs;
+    if (a.M == 1) {                                                            // :357-373 mean_error
+        double sum_err = 0;
+        for (u64 j = start; j <= end; j++)
+            if (a.bwt[j] != TERM) sum_err = sum_err + a.powtab[a.qual[j]];
+        double avg_err = sum_err / (double)base_num;
+        int lo = 0, hi = a.qthrN - 1;                                          // first k with qthr[k] <= avg_err
+        while (lo < hi) { int mid = (lo + hi) >> 1; if (a.qthr[mid] <= avg_err) hi = mid; else lo = mid + 1; }
+        int q = a.qthrLo + lo;
+        newqs = a.ext ? (int)(signed char)(u8)((u8)q + 33) : (int)(signed char)(q + 33);
+    } else if (a.M == 2) {
+        newqs = (int)(signed char)a.v;                                         // :467
+    } else if (a.M == 3) {                                                     // :323-338 avg_qs
+        int sum = 0;
+        for (u64 j = start; j <= end; j++)
+            if (a.bwt[j] != TERM) sum += (int)(signed char)a.qual[j];
+        if (sum == 0) newqs = 0;
+        else if (a.ext) newqs = (int)(signed char)(u8)roundf((float)sum / (float)base_num);   // bfq_ext.cpp:496
+        else newqs = (int)(signed char)(int)((u64)(long long)sum / base_num);
+    } else {                                                                   // :342-353 max_qs
+        int mx = 0;
+        for (u64 j = start; j <= end; j++)
+            if (a.bwt[j] != TERM) { int q = (int)(signed char)a.qual[j]; if (q > mx) mx = q; }
+        newqs = mx;
+    }
+
+    u8 Freq[5];
+    int nf = 0, nnn = 0;                                                       // :480-499
+    for (int s = 0; s < 5; s++)
+        if (freqs[s] > 0) {
+            nnn++;
+            u32 perc = (u32)((100ull * freqs[s]) / base_num) & 0xFFu;
+            if ((float)perc >= (float)a.f) Freq[nf++] = dna5(s);
+        }
+    if (nnn == 1) st.alleq++;
+    if (nf >= 3) { atomicAdd(&a.cnt->errFreq3, 1ull); return; }               // :505 assert
+
+    if (nf == 0) { st.disc++; return; }
+    if (nf == 1) {
+        if (Freq[0] == 'N') st.disc++;
+        else mod_smooth(a, start, end, Freq[0], newqs, lowQS, st);
+        return;
+    }
+    if (base_num < (u64)(long long)a.m) { st.disc++; return; }                   // :520
+    if (Freq[0] == 'N') { mod_smooth(a, start, end, Freq[1], newqs, lowQS, st); st.mod++; return; }
+    if (Freq[1] == 'N') { mod_smooth(a, start, end, Freq[0], newqs, lowQS, st); st.mod++; return; }
+
+    // :542-565 the symbols preceding the two frequent bases: bwt[LF(j)]
+    u8 symbPrec[2] = {0, 0};
+    u32 fr[2] = {0, 0};
+    for (u64 j = start; j <= end; j++) {
+        u8 b = a.bwt[j];
+        int w = (b == Freq[0]) ? 0 : ((b == Freq[1]) ? 1 : -1);
+        if (w < 0) continue;
+        u64 nx = rank_lf(a.R, j, bfq_base_code(b));
+        u8 ch = a.bwt[nx];
+        if (ch != TERM && ch != 'N') { fr[w] |= 1u << ord5(ch); symbPrec[w] = ch; }
+    }
+    if (__popc(fr[0] & 15u) == 1 && __popc(fr[1] & 15u) == 1 && symbPrec[0] != symbPrec[1]) {   // :568
+        st.mod++;
+        for (u64 j = start; j <= end; j++) {
+            u8 b = a.bwt[j];
+            if (b == TERM) continue;
+            if (b != Freq[0] && b != Freq[1] && !((lowQS >> ord5(b)) & 1u)) {
+                u8 ch = a.bwt[rank_lf(a.R, j, bfq_base_code(b))];
+                if (ch == symbPrec[0]) { a.modsym[j] = Freq[0]; st.modb++; }
+                else if (ch == symbPrec[1]) { a.modsym[j] = Freq[1]; st.modb++; }
+            } else if (b == Freq[0] || b == Freq[1]) {
+                a.qual[j] = (u8)newqs; st.qs++;
+            } else if (newqs < (int)(signed char)a.qual[j]) {
+                a.qual[j] = (u8)newqs; st.qs++;
+            }
+        }
+    } else {
+        st.amb++;
+    }
+}
+
+// statistics of one cluster go straight to the workgroup's LDS counters (bfq_int.cpp:53-62)
+__device__ __forceinline__ void process_cluster(const ClusterArgs &a, u64 start, u64 end, u32 *shst)
+{
+    ClStat st = {0, 0, 0, 0, 0, 0, 0, 0};
+    process_cluster_body(a, start, end, st);
+    if (st.clust) atomicAdd(&shst[0], st.clust);
+    if (st.disc) atomicAdd(&shst[1], st.disc);
+    if (st.amb) atomicAdd(&shst[2], st.amb);
+    if (st.mod) atomicAdd(&shst[3], st.mod);
+    if (st.alleq) atomicAdd(&shst[4], st.alleq);
+    if (st.bases) atomicAdd(&shst[5], st.bases);
+    if (st.qs) atomicAdd(&shst[6], st.qs);
+    if (st.modb) atomicAdd(&shst[7], st.modb);
+}
+
+__global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
+{
+    __shared__ u32 shst[8];
+    if (threadIdx.x < 8) shst[threadIdx.x] = 0;
+    __syncthreads();
+    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 1 && r < a.n && a.in[r] && !a.in[r - 1]) {
+        u64 e = r;
+        while (e + 1 < a.n && a.in[e + 1]) e++;
+        process_cluster(a, r - 1, e, shst);
+    }
+    __syncthreads();
+    if (threadIdx.x < 8 && shst[threadIdx.x]) atomicAdd(&a.cnt->stats[threadIdx.x], (u64)shst[threadIdx.x]);
+}
+
+void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
+{
+    if (!n) return;
+    KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, ceil_div(n, 256), 256, lcp, n, K, in);
+}
+
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, u8 *qual, const u8 *in, u64 n, u8 *modsym)
+{
+    if (!n) return;
+    ClusterArgs a;
+    a.R = R; a.bwt = bwt; a.qual = qual; a.in = in; a.modsym = modsym; a.n = n;
+    a.m = c->P.m; a.v = c->P.v; a.f = c->P.f; a.t = c->P.t; a.term = c->P.term & 0xFF; a.M = c->P.M; a.ext = c->P.ext;
+    a.powtab = c->d_powtab; a.qthr = c->d_qthr; a.qthrLo = c->qthrLo; a.qthrN = c->qthrN;
+    a.cnt = c->d_cnt;
+    HIP_CHECK(hipMemsetAsync(modsym, 0, n, c->stream));
+    KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, ceil_div(n, 256), 256, a);
+}

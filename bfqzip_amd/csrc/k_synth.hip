@@ -1,0 +1,42 @@
+// k_synth.hip -- device side of the seeded synthetic-read generator (bfq_synth.h).
+#include "bfq_internal.h"
+#include "bfq_device.h"
+#include "bfq_synth.h"
+
+__global__ __launch_bounds__(256) void k_synth_lens(bfq_synth s, u32 *__restrict__ lens)
+{
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < s.N) lens[i] = bfq_synth_len(&s, i);
+}
+
+// one wave per read
+__global__ __launch_bounds__(256) void k_synth_reads(bfq_synth s, const u64 *__restrict__ roff, u8 *__restrict__ bases,
+                                                     u8 *__restrict__ quals)
+{
+    u32 lane = bfq_lane();
+    u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 i = wave; i < s.N; i += nwaves) {
+        u64 b = roff[i];
+        u32 len = (u32)(roff[i + 1] - b);
+        for (u32 k = lane; k < len; k += 64) {
+            u8 bb, qq;
+            bfq_synth_base(&s, i, len, k, &bb, &qq);
+            bases[b + k] = bb;
+            quals[b + k] = qq;
+        }
+    }
+}
+
+void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, u64 *d_roff)
+{
+    if (!s->N) { HIP_CHECK(hipMemsetAsync(d_roff, 0, sizeof(u64), c->stream)); return; }
+    size_t m = c->mark();
+    u32 *lens = c->alloc<u32>(s->N);
+    KLAUNCH(c, K_SYNTH, 4.0 * (double)s->N, k_synth_lens, ceil_div(s->N, 256), 256, *s, lens);
+    bfq_exscan_u32(c, lens, d_roff, s->N, d_roff + s->N);
+    u64 waves = s->N < (1u << 18) ? s->N : (1u << 18);
+    KLAUNCH(c, K_SYNTH, 2.0 * (double)s->N * s->Lmax, k_synth_reads, ceil_div(waves, 4), 256, *s, (const u64 *)d_roff,
+            d_bases, d_quals);
+    c->release(m);
+}

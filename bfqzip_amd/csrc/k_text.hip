@@ -1,0 +1,84 @@
+// k_text.hip -- reads -> terminated text of symbol codes -> 3-bit packed text ->
+// (21-symbol key, payload) pairs, one per suffix.  Pure streaming kernels.
+//
+// Replaces the input stage of the absent step-1 tool (call site BFQzip.py:178-189):
+// the text is the read collection with one terminator per read, no global end
+// marker (gsufsort built with TERMINATOR=0, reference Makefile:18).
+#include "bfq_internal.h"
+#include "bfq_device.h"
+
+// one wave per read: symbol codes + qualities into terminated text order
+__global__ __launch_bounds__(256) void k_text_from_reads(const u8 *__restrict__ bases, const u8 *__restrict__ quals,
+                                                         const u64 *__restrict__ roff, u64 N, u8 *__restrict__ T8,
+                                                         u8 *__restrict__ Q8, DevCounters *cnt)
+{
+    u32 lane = bfq_lane();
+    u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    bool bad = false, tooLong = false;
+    for (u64 i = wave; i < N; i += nwaves) {
+        u64 b = roff[i], e = roff[i + 1];
+        u64 t0 = b + i, len = e - b;
+        if (len > BFQ_MAX_READ_LEN) tooLong = true;
+        for (u64 k = lane; k < len; k += 64) {
+            u32 code = bfq_base_code(bases[b + k]);
+            if (code == BFQ_CODE_INVALID) { bad = true; code = 4; }
+            T8[t0 + k] = (u8)code;
+            Q8[t0 + k] = quals[b + k];
+        }
+        if (lane == 0) { T8[t0 + len] = 0; Q8[t0 + len] = (u8)'#'; }
+    }
+    if (bad) atomicAdd(&cnt->errSymbol, 1ull);
+    if (tooLong) atomicAdd(&cnt->errTooLong, 1ull);
+}
+
+// one thread per packed word: 21 codes -> 63 bits, first symbol in the top field
+__global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n, u64 *__restrict__ text3, u64 nwords)
+{
+    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= nwords) return;
+    u64 p0 = w * BFQ_SYMS_PER_WORD;
+    u64 v = 0;
+#pragma unroll
+    for (int j = 0; j < BFQ_SYMS_PER_WORD; j++) {
+        u64 p = p0 + j;
+        u64 c = (p < n) ? (u64)T8[p] : 0ull;
+        v = (v << 3) | c;
+    }
+    text3[w] = v;
+}
+
+// one thread per suffix: masked 21-symbol key + payload (position, previous symbol, its quality)
+__global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, const u8 *__restrict__ Q8,
+                                                    const u64 *__restrict__ text3, u64 n, u64 *__restrict__ keys,
+                                                    u64 *__restrict__ vals)
+{
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    u32 pc = 0, pq = (u32)'#';
+    if (p > 0) {
+        pc = T8[p - 1];
+        if (pc) pq = Q8[p - 1];
+    }
+    keys[p] = bfq_key_at(text3, p);
+    vals[p] = bfq_pack_val(p, pc, pq);
+}
+
+void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 n, u8 *T8,
+                    u8 *Q8, u64 *text3, u64 nwords)
+{
+    if (N) {
+        u64 waves = N < (1u << 18) ? N : (1u << 18);
+        u64 blocks = ceil_div(waves, 4);
+        KLAUNCH(c, K_TEXT, 4.0 * (double)(n - N), k_text_from_reads, blocks, 256, d_bases, d_quals, d_roff, N, T8, Q8,
+                c->d_cnt);
+    }
+    KLAUNCH(c, K_PACK, (double)n + 8.0 * (double)nwords, k_pack3, ceil_div(nwords, 256), 256, (const u8 *)T8, n, text3,
+            nwords);
+}
+
+void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u64 *keys, u64 *vals)
+{
+    if (!n) return;
+    KLAUNCH(c, K_KEYS, 18.5 * (double)n, k_build_keys, ceil_div(n, 256), 256, T8, Q8, text3, n, keys, vals);
+}

@@ -1,0 +1,142 @@
+/*
+ * bfqzip_hip.h -- C-ABI of libbfqhip.so: the MI355X (gfx950) implementation of
+ * BFQzip's hot path  eBWT build -> positional clusters -> smoothing -> LF inversion.
+ *
+ * The reference has no in-process API for this path: its boundary is the
+ * process boundary between the Python drivers and four executables
+ * (BFQzip.py:178-189,206-228; BFQzip_ext.py:165-183,199-220).  The entry points
+ * below are what those executables' main() functions reduce to once file I/O is
+ * taken out; the drop-in front-ends in bfqzip_amd/csrc/cli/ (gsufsort, eGap,
+ * bfq_int, bfq_ext) are thin argv/file wrappers over them.
+ *
+ * Conventions: plain pointers and sizes, no torch types.  Every function
+ * returns 0 on success and a negative BFQ_E_* code on failure;
+ * bfq_last_error() gives the message.  A context owns one GPU stream and one
+ * device workspace; it is not thread-safe, use one context per thread/GPU.
+ * "h_" = host pointer, "d_" = device pointer (hipMalloc'ed / torch storage).
+ */
+#ifndef BFQZIP_HIP_H
+#define BFQZIP_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BFQ_OK              0
+#define BFQ_E_ARG          -1   /* bad argument                                            */
+#define BFQ_E_HIP          -2   /* HIP runtime error / no device                           */
+#define BFQ_E_SYMBOL       -3   /* symbol outside {A,C,G,T,N,TERM} (dna_string_n.hpp:87-93) */
+#define BFQ_E_NOT_EBWT     -4   /* eBWT does not invert / not in #_i<#_j<A<C<G<N<T order   */
+#define BFQ_E_TOO_LONG     -5   /* read longer than BFQ_MAX_READ_LEN                       */
+#define BFQ_E_FREQ3        -6   /* three frequent symbols: assert of bfq_int.cpp:505        */
+#define BFQ_E_NOMEM        -7
+
+#define BFQ_MAX_READ_LEN 65000  /* LCP is held in 16 bits (reference: LONGEST 10000, bfq_int.cpp:30) */
+
+/* Run-time form of the reference's getopt flags (bfq_int.cpp:883-935) and of its
+ * compile-time knobs -DM / -DB (src_int_mem/Makefile:13-23). */
+typedef struct bfq_params {
+    int32_t K;      /* -k  minimum LCP inside clusters            default 16        */
+    int32_t m;      /* -m  minimum cluster length                 default 2         */
+    int32_t v;      /* -v  replacement quality (ASCII code, M=2)  default '>' (62)  */
+    int32_t f;      /* -f  frequent-symbol percentage             default 40        */
+    int32_t t;      /* -t  trusted-quality threshold (phred)      default 20        */
+    int32_t term;   /* -s  terminator byte in the eBWT            default '#' (35)  */
+    int32_t M;      /* 0 max, 1 mean error, 2 constant, 3 average default 2         */
+    int32_t B;      /* 1 = Illumina 8-level binning               default 0         */
+    int32_t ext;    /* 1 = bfq_ext arithmetic for M=3 (bfq_ext.cpp:496)             */
+    int32_t reserved[7];
+} bfq_params;
+
+/* Counters printed by bfq_int.cpp:1004-1019. */
+typedef struct bfq_stats {
+    uint64_t num_clust, num_clust_discarded, num_clust_amb_discarded, num_clust_mod,
+             num_clust_alleq, bases_inside, qs_smoothed, modified;
+    uint64_t n_rows, n_reads, n_segments, n_big_segments;
+} bfq_stats;
+
+typedef struct bfq_ctx bfq_ctx;
+
+void     bfq_default_params(bfq_params *p);
+bfq_ctx *bfq_create(int device, const bfq_params *p);          /* NULL on failure: see bfq_create_error() */
+const char *bfq_create_error(void);
+void     bfq_destroy(bfq_ctx *c);
+int      bfq_set_params(bfq_ctx *c, const bfq_params *p);
+const char *bfq_last_error(bfq_ctx *c);
+void    *bfq_stream(bfq_ctx *c);                                /* the hipStream_t all kernels run on */
+int      bfq_device_count(void);
+
+/* ---- step 1: replaces `gsufsort <fq> --bwt --qs -o OUT` (BFQzip.py:184) and
+ *      `eGap <fq> --em --mem M --qs -o OUT --lcp --lbytes 1` (BFQzip_ext.py:177).
+ * h_bases/h_quals: the reads back to back (lines 2 and 4 of each record),
+ * h_read_off[N+1]: offsets.  Outputs (host, n = h_read_off[N]+N entries each):
+ * h_bwt, h_bwtqs; h_lcp16 (exact, may be NULL).  term_out: byte written for the
+ * terminator ('#' for gsufsort, 0 for eGap). */
+int bfq_build_ebwt(bfq_ctx *c, const uint8_t *h_bases, const uint8_t *h_quals,
+                   const uint64_t *h_read_off, uint64_t N, int term_out,
+                   uint8_t *h_bwt, uint8_t *h_bwtqs, uint16_t *h_lcp16);
+
+/* ---- steps 2-4: replaces `bfq_int -e OUT.bwt -q OUT.bwt.qs -o OUT.fq ...`
+ *      (BFQzip.py:215-222; main() bfq_int.cpp:875-1062) when h_lcp is NULL, and
+ *      `bfq_ext -e .. -q .. -a OUT.1.lcp ...` (BFQzip_ext.py:208-214) when h_lcp
+ *      is given (lcp_bytes = 1, 2 or 4 bytes per entry, little endian).
+ * Outputs: h_out_bases/h_out_quals (n - N bytes each), h_out_read_off[N+1].
+ * Call bfq_count_reads() first to size them. */
+int bfq_count_reads(const uint8_t *h_bwt, uint64_t n, int term, uint64_t *N);
+int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs,
+                      const void *h_lcp, int lcp_bytes, uint64_t n,
+                      uint8_t *h_out_bases, uint8_t *h_out_quals, uint64_t *h_out_read_off,
+                      bfq_stats *st);
+
+/* ---- fused path (no intermediate files): reads in -> smoothed reads out. */
+int bfq_run_reads(bfq_ctx *c, const uint8_t *h_bases, const uint8_t *h_quals,
+                  const uint64_t *h_read_off, uint64_t N,
+                  uint8_t *h_out_bases, uint8_t *h_out_quals, bfq_stats *st);
+
+/* Same with everything resident in HBM (what bench.py times).  d_out_* may
+ * alias nothing else; total = number of bases = d_read_off[N] (given by the
+ * caller so that no synchronising read-back is needed). */
+int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_quals,
+                         const uint64_t *d_read_off, uint64_t N, uint64_t total,
+                         uint8_t *d_out_bases, uint8_t *d_out_quals, bfq_stats *st);
+
+/* Device-resident eBWT of the last bfq_run_reads*() / bfq_build_ebwt() call
+ * (valid until the next call on the context): copies to host. Any may be NULL. */
+int bfq_fetch_ebwt(bfq_ctx *c, uint8_t *h_bwt, uint8_t *h_bwtqs_smoothed, uint16_t *h_lcp16);
+
+/* ---- synthetic reads (seeded, counter based; DESIGN.md "synthetic workload").
+ * Fixed length L when Lmin == Lmax.  Host and device versions produce identical
+ * bytes.  read_off[N+1] is written too. */
+typedef struct bfq_synth {
+    uint64_t seed;
+    uint64_t N;          /* reads                                   */
+    uint32_t Lmin, Lmax; /* read length range (inclusive)           */
+    uint32_t coverage;   /* genome length = N*Lavg/coverage         */
+    uint32_t err_ppm;    /* substitution errors, per million bases  */
+    uint32_t n_ppm;      /* 'N' calls, per million bases            */
+    uint32_t snp_every;  /* haplotype SNP period (~1000)            */
+    uint32_t dsnp_every; /* adjacent double-SNP period (~10000)     */
+    uint32_t both_strands;
+    uint32_t reserved[5];
+} bfq_synth;
+void bfq_synth_default(bfq_synth *s, uint64_t N, uint32_t L);
+uint64_t bfq_synth_total(const bfq_synth *s);                    /* total bases = read_off[N] */
+int bfq_synth_host(const bfq_synth *s, uint8_t *h_bases, uint8_t *h_quals, uint64_t *h_read_off);
+int bfq_synth_device(bfq_ctx *c, const bfq_synth *s, uint8_t *d_bases, uint8_t *d_quals,
+                     uint64_t *d_read_off);
+
+/* ---- profiling: per-kernel HIP-event times accumulated over the calls since
+ * the last bfq_prof_reset() (events recorded on bfq_stream()). */
+int  bfq_prof_enable(bfq_ctx *c, int on);
+void bfq_prof_reset(bfq_ctx *c);
+int  bfq_prof_count(bfq_ctx *c);
+int  bfq_prof_get(bfq_ctx *c, int idx, char *name, int name_cap, double *total_ms,
+                  uint64_t *launches, double *alg_bytes_total);
+
+uint64_t bfq_workspace_bytes(bfq_ctx *c);      /* current device workspace size */
+const char *bfq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,143 @@
+"""GPU parity tests: libbfqhip.so (through its C-ABI) against the CPU oracle and the
+golden vectors of the compiled reference.  Bit-exact: integer / byte / index work;
+the only floating point (M=1) is evaluated through host-libm tables and must be
+bit-exact as well."""
+import os
+import numpy as np
+import pytest
+from bfqzip_amd import api, fastq
+from tests import util
+
+pytestmark = pytest.mark.gpu
+IDX = util.golden_index()
+CASES = [(name, key) for name in IDX for key in IDX[name]["out"]]
+
+
+def _engine_params(d):
+    return dict(k=d["k"], m=d["m"], v=d["v"], f=d["f"], t=d["t"], M=d["M"], B=d["B"])
+
+
+@pytest.mark.parametrize("name", list(IDX))
+def test_build_ebwt_matches_golden(engine, name):
+    b, q, r, h, bwt, qs, lcp = util.golden_set(name)
+    bwt2, qs2, lcp2 = engine.build_ebwt(b, q, r)
+    assert np.array_equal(bwt2, bwt)
+    assert np.array_equal(qs2, qs)
+    assert np.array_equal(lcp2, lcp)
+
+
+@pytest.mark.parametrize("name,key", CASES)
+def test_smooth_invert_matches_reference_output(engine, name, key):
+    b, q, r, h, bwt, qs, lcp = util.golden_set(name)
+    d, hdr = util.parse_case(key)
+    engine.set_params(**_engine_params(d))
+    ob, oq, oroff, st = engine.smooth_invert(bwt, qs)                 # bfq_int mode: LCP deduced
+    assert util.md5(fastq.format_fastq(ob, oq, oroff, h if hdr else None)) == IDX[name]["out"][key]
+    ob2, oq2, oroff2, st2 = engine.smooth_invert(bwt, qs, lcp)       # bfq_ext mode: LCP given
+    assert np.array_equal(ob, ob2) and np.array_equal(oq, oq2) and np.array_equal(oroff, oroff2)
+    ob3, oq3, st3 = engine.run_reads(b, q, r)                        # fused
+    assert np.array_equal(ob, ob3) and np.array_equal(oq, oq3)
+    for k in ("num_clust", "bases_inside", "qs_smoothed", "modified"):
+        assert st[k] == st2[k] == st3[k]
+
+
+def _check_against_oracle(engine, orc, b, q, r, **par):
+    full = dict(k=16, m=2, v=ord(">"), f=40, t=20, M=2, B=0)
+    full.update(par)
+    engine.set_params(**full)
+    p = orc.params(K=full["k"], m=full["m"], v=full["v"], f=full["f"], t=full["t"], M=full["M"], B=full["B"])
+    bwt, qs, lcp = orc.build_ebwt(b, q, r)
+    gb, gq, gl = engine.build_ebwt(b, q, r)
+    assert np.array_equal(gb, bwt), "bwt"
+    assert np.array_equal(gq, qs), "qs"
+    assert np.array_equal(gl.astype(np.uint32), lcp), "lcp"
+    ob, oq, st = orc.run_reads(b, q, r, p)
+    hb, hq, hst = engine.run_reads(b, q, r)
+    assert np.array_equal(hb, ob), "bases"
+    assert np.array_equal(hq, oq), "quals"
+    for k in st:
+        assert st[k] == hst[k], k
+    if len(bwt):
+        sb, sq, sroff, sst = engine.smooth_invert(bwt, qs)
+        assert np.array_equal(sb, ob) and np.array_equal(sq, oq) and np.array_equal(sroff, r)
+    return hst
+
+
+@pytest.mark.parametrize("M,B", [(M, B) for M in range(4) for B in range(2)])
+def test_synthetic_all_modes(engine, orc, M, B):
+    sp = api.synth_spec(3000, 50, seed=100 + M * 2 + B, coverage=25)
+    b, q, r = api.synth_host(sp)
+    st = _check_against_oracle(engine, orc, b, q, r, M=M, B=B, m=5)
+    assert st["num_clust"] > 100
+
+
+def test_variable_length_two_symbol_branch(engine, orc):
+    sp = api.synth_spec(4000, 20, Lmax=70, seed=5, coverage=40, err_ppm=20000, n_ppm=15000, snp_every=97, dsnp_every=131)
+    b, q, r = api.synth_host(sp)
+    st = _check_against_oracle(engine, orc, b, q, r, m=5)
+    assert st["num_clust_mod"] > 0            # the two-frequent-symbol "processed" branch ran
+
+
+def test_random_small_sets(engine, orc):
+    rng = np.random.default_rng(2024)
+    for it in range(40):
+        nreads = int(rng.integers(1, 300)); lmax = int(rng.integers(1, 60))
+        b, q, r = util.random_reads(rng, nreads, 1, lmax)
+        _check_against_oracle(engine, orc, b, q, r, M=int(rng.integers(0, 4)), B=int(rng.integers(0, 2)),
+                              k=int(rng.choice([1, 2, 3, 5, 8, 16])), m=int(rng.choice([2, 3, 5, 9])),
+                              v=int(rng.choice([62, 53, 73])), t=int(rng.choice([5, 20, 35])),
+                              f=int(rng.choice([40, 50, 70])))
+
+
+def test_edge_cases(engine, orc):
+    A = lambda s: np.frombuffer(s, np.uint8)
+    one = (A(b"ACGTN"), A(b"IIII#"), np.array([0, 5], np.uint64))
+    single_base = (A(b"A"), A(b"I"), np.array([0, 1], np.uint64))
+    with_empty = (A(b"ACGTAC"), A(b"IIIIII"), np.array([0, 3, 3, 6], np.uint64))     # an empty read in the middle
+    for b, q, r in (one, single_base, with_empty):
+        _check_against_oracle(engine, orc, b, q, r, m=2, k=1)
+    # many identical reads: segments far larger than a wavefront (k_refine_big), ties by read index
+    rd = A(b"ACGTTGCAACGTACGTTTGACCAGTACGATCGATCGTAGCTAGCTAGCATCGATCAGCTACGATCGATCAGCATCGA")
+    nrep = 300
+    b = np.tile(rd, nrep); q = np.tile(np.arange(len(rd), dtype=np.uint8) % 40 + 35, nrep)
+    r = np.arange(nrep + 1, dtype=np.uint64) * len(rd)
+    st = _check_against_oracle(engine, orc, b, q, r, m=5)
+    assert st["n_big_segments"] > 0
+    # low complexity: poly-A of different lengths plus a few N-only reads
+    reads = [b"A" * L for L in (1, 2, 30, 64, 65, 100, 100, 100, 7)] + [b"N" * 5, b"NNNNNNNNNNNNNNNNNNNNNNNNN"] + [b"A" * 90] * 70
+    b = A(b"".join(reads)); q = np.full(len(b), 70, np.uint8)
+    r = np.zeros(len(reads) + 1, np.uint64); r[1:] = np.cumsum([len(x) for x in reads])
+    _check_against_oracle(engine, orc, b, q, r, m=2, k=3)
+
+
+def test_errors_are_loud(engine):
+    A = lambda s: np.frombuffer(s, np.uint8)
+    with pytest.raises(api.BfqError) as e:
+        engine.run_reads(A(b"ACGX"), A(b"IIII"), np.array([0, 4], np.uint64))
+    assert e.value.code == -3
+    with pytest.raises(api.BfqError):
+        engine.smooth_invert(A(b"AC#G"), A(b"IIII"))          # not an eBWT in suffix order
+
+
+def test_device_resident_and_synth_device(engine, orc):
+    torch = pytest.importorskip("torch")
+    sp = api.synth_spec(20000, 100, seed=77)
+    hb, hq, hr = api.synth_host(sp)
+    total = len(hb)
+    dev = torch.device("cuda:0")
+    db = torch.empty(total, dtype=torch.uint8, device=dev); dq = torch.empty_like(db)
+    dr = torch.empty(sp.N + 1, dtype=torch.int64, device=dev)
+    engine.synth_device(sp, db.data_ptr(), dq.data_ptr(), dr.data_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(db.cpu().numpy(), hb) and np.array_equal(dq.cpu().numpy(), hq)
+    assert np.array_equal(dr.cpu().numpy().astype(np.uint64), hr)
+    ob = torch.empty_like(db); oq = torch.empty_like(db)
+    engine.set_params(m=5)
+    st = engine.run_reads_device(db.data_ptr(), dq.data_ptr(), dr.data_ptr(), sp.N, total, ob.data_ptr(), oq.data_ptr())
+    torch.cuda.synchronize()
+    eb, eq, est = orc.run_reads(hb, hq, hr, orc.params(m=5))
+    assert np.array_equal(ob.cpu().numpy(), eb) and np.array_equal(oq.cpu().numpy(), eq)
+    for k in est:
+        assert est[k] == st[k]
+    prof = engine.prof()
+    assert "k_radix_scatter" in prof and prof["k_radix_scatter"]["launches"] >= 8
