@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- Mbases/s of the hot path (eBWT build -> clusters/smoothing -> LF inversion)
+on synthetic short reads, one process per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload 30Mx150|1Mx100|<reads>x<len>]
+
+A step = one pass of the whole path over one block of reads resident in HBM
+(bfq_run_reads_device).  N > 1: every rank owns an independent block (the
+BFQzip_parallel.py split: blocks never interact) -> weak scaling, no data-path
+collective; only the block sizes are exchanged.  Prints ONE JSON line on rank 0.
+"""
+import argparse, json, os, subprocess, sys, tempfile, time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def alg_bytes_per_base(L):
+    """A(L) = (L+1)/L * (352.7 + 3(L+1)/16) bytes per base."""
+    return (L + 1) / L * (352.7 + 3 * (L + 1) / 16)
+
+
+def parse_workload(w):
+    a, b = w.lower().split("x")
+    mult = 1
+    if a.endswith("m"):
+        a, mult = a[:-1], 1_000_000
+    elif a.endswith("k"):
+        a, mult = a[:-1], 1_000
+    return int(float(a) * mult), int(b)
+
+
+def cpu_baseline(api, orc, L, seed, sample_reads, params):
+    """Reference CPU path on a bounded sample of the same workload, 1 core.
+    step 1: the oracle's suffix sorter (stands in for gsufsort, an absent submodule);
+    steps 2-4: the reference bfq_int compiled from /root/reference (oracle/_ref) if
+    present ("reference"), else the oracle restatement ("port")."""
+    from bfqzip_amd import fastq
+    sp = api.synth_spec(sample_reads, L, seed=seed)
+    b, q, r = api.synth_host(sp)
+    t0 = time.perf_counter()
+    bwt, qs, lcp = orc.build_ebwt(b, q, r)
+    t1 = time.perf_counter()
+    kind = "port"
+    ref = orc.ref_binary(params["M"], params["B"])
+    out = None
+    if ref is not None:
+        d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+        try:
+            bwt.tofile(d + "/x.bwt"); qs.tofile(d + "/x.bwt.qs")
+            t2 = time.perf_counter()
+            subprocess.check_call([ref, "-e", d + "/x.bwt", "-q", d + "/x.bwt.qs", "-o", d + "/o.fq", "-m", str(params["m"])],
+                                  stdout=subprocess.DEVNULL, timeout=1200)
+            t3 = time.perf_counter()
+            out = open(d + "/o.fq", "rb").read()
+            kind = "reference"
+        except Exception:
+            out = None
+        finally:
+            for f in os.listdir(d):
+                os.unlink(os.path.join(d, f))
+            os.rmdir(d)
+    if out is None:
+        t2 = time.perf_counter()
+        ob, oq, oroff, st = orc.smooth_invert(bwt, qs, lcp.astype(np.uint32), orc.params(m=params["m"], M=params["M"], B=params["B"]))
+        t3 = time.perf_counter()
+        out = fastq.format_fastq(ob, oq, oroff)
+    secs = (t1 - t0) + (t3 - t2)
+    return {"value": len(b) / 1e6 / secs, "unit": "Mbases/s", "cores": 1, "kind": kind,
+            "sample": f"{sample_reads}x{L} synthetic reads of the same generator; step 1 by the oracle's suffix sorter "
+                      f"(stand-in for gsufsort, absent) {t1 - t0:.2f}s + steps 2-4 {t3 - t2:.2f}s"}, (b, q, r, out)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("BFQ_BENCH_WORKLOAD", "30Mx150"))
+    ap.add_argument("--sample-reads", type=int, default=100_000)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--M", type=int, default=2)
+    ap.add_argument("--B", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from bfqzip_amd import api, fastq
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    N, L = parse_workload(args.workload)
+    B = args.B if args.B is not None else (1 if (N, L) == (30_000_000, 150) else 0)   # BASELINE.json configs[2]: B=1
+    par = dict(k=16, m=5, v=ord(">"), f=40, t=20, M=args.M, B=B)                      # -m 5: what BFQzip.py passes
+    eng = api.Engine(local, **par)
+    seed = 20240807 + rank
+    sp = api.synth_spec(N, L, seed=seed)
+    total = N * L
+    db = torch.empty(total, dtype=torch.uint8, device=dev); dq = torch.empty_like(db)
+    dr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    ob = torch.empty_like(db); oq = torch.empty_like(db)
+    eng.synth_device(sp, db.data_ptr(), dq.data_ptr(), dr.data_ptr())
+    torch.cuda.synchronize()
+
+    def step():
+        return eng.run_reads_device(db.data_ptr(), dq.data_ptr(), dr.data_ptr(), N, total, ob.data_ptr(), oq.data_ptr())
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    st = None
+    for _ in range(args.warmup):
+        st = step()
+    eng.prof_reset()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = step()
+        if world > 1:                                   # the only exchange: per-block output sizes (8 integers)
+            sz = torch.tensor([total], dtype=torch.int64, device=dev)
+            lst = [torch.empty_like(sz) for _ in range(world)]
+            dist.all_gather(lst, sz)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    prof = eng.prof()
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = world * total / 1e6 / (dt / args.steps)
+        # dominant kernel = largest accumulated HIP-event time over the timed region
+        dom = max(prof.items(), key=lambda kv: kv[1]["ms"])
+        dname, d = dom
+        avg_ms = d["ms"] / d["launches"]
+        ach = d["alg_bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": dname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": round(avg_ms, 4), "launches": int(d["launches"]),
+                "alg_bytes_per_launch": d["alg_bytes"] / d["launches"],
+                "job_alg_bytes_per_base": round(alg_bytes_per_base(L), 1),
+                "job_frac": round(alg_bytes_per_base(L) * (total / (dt / args.steps)) / (HBM_PEAK_GBS * 1e9), 4)}
+        kern = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
+        res = {"metric": "Mbases/s end-to-end (eBWT+cluster+LF)", "value": round(value, 2), "unit": "Mbases/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 integer",
+               "data": "synthetic (seeded generator, 30x coverage, 1% errors, 0.1% N)",
+               "config": {"workload": f"{N}x{L}bp synthetic reads per GPU, M={args.M} B={B} -m 5 K=16", "reads_per_gpu": N,
+                          "read_len": L, "rows_per_gpu": N * (L + 1), "parallelism": f"{world} independent blocks"},
+               "roofline": roof, "kernel_ms_per_step": kern,
+               "stats": {k: st[k] for k in ("num_clust", "bases_inside", "qs_smoothed", "modified", "n_segments", "n_big_segments")},
+               "workspace_gib": round(eng.workspace_bytes() / 2**30, 2)}
+        if world == 1 and not args.no_cpu:
+            from oracle import orc
+            cb, (sb, sq, sr, sout) = cpu_baseline(api, orc, L, seed, min(args.sample_reads, N), par)
+            res["cpu_baseline"] = cb
+            # the GPU path on the same sample must reproduce the CPU output byte for byte
+            gb, gq, gst = eng.run_reads(sb, sq, sr)
+            res["sample_parity"] = bool(fastq.format_fastq(gb, gq, sr) == sout)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

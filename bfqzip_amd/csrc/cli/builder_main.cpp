@@ -1,0 +1,65 @@
+// builder_main.cpp -- drop-in for the reference's step-1 tools, over libbfqhip.so:
+//   gsufsort <in.fastq> --bwt --qs -o <OUT>                        (BFQzip.py:184)
+//       -> <OUT>.bwt, <OUT>.bwt.qs   (terminator '#')
+//   eGap <in.fastq> --em --mem <MB> --qs -o <OUT> --lcp --lbytes 1  (BFQzip_ext.py:172-177)
+//       -> <OUT>.bwt (terminator byte 0), <OUT>.bwt.qs, <OUT>.<lbytes>.lcp
+// Exit status 0 on success, 1 on any error (the drivers check it, BFQzip.py:328-336).
+#include "cli_common.h"
+
+int main(int argc, char **argv)
+{
+#ifdef BFQ_TOOL_EGAP
+    const char *tool = "eGap";
+    int term = 0;
+#else
+    const char *tool = "gsufsort";
+    int term = '#';
+#endif
+    std::string in, out;
+    bool wantLcp = false;
+    int lbytes = 1;
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if (a == "-o" || a == "--output") { if (++i < argc) out = argv[i]; }
+        else if (a == "--mem" || a == "-m" || a == "--docs" || a == "-d") { ++i; }
+        else if (a == "--lbytes") { if (++i < argc) lbytes = atoi(argv[i]); }
+        else if (a == "--lcp") wantLcp = true;
+        else if (a.size() && a[0] == '-') { /* --bwt --qs --em --rev ...: accepted, nothing to do */ }
+        else if (in.empty()) in = a;
+    }
+    if (in.empty()) { fprintf(stderr, "%s: no input FASTQ\n", tool); return 1; }
+    if (out.empty()) out = in;
+    if (lbytes != 1 && lbytes != 2 && lbytes != 4) { fprintf(stderr, "%s: --lbytes must be 1, 2 or 4\n", tool); return 1; }
+    std::vector<uint8_t> buf, bases, quals;
+    std::vector<uint64_t> off;
+    std::string err;
+    if (!read_file(in, buf)) { fprintf(stderr, "%s: cannot read %s\n", tool, in.c_str()); return 1; }
+    if (!parse_fastq(buf, bases, quals, off, err)) { fprintf(stderr, "%s: %s: %s\n", tool, in.c_str(), err.c_str()); return 1; }
+    buf.clear(); buf.shrink_to_fit();
+    uint64_t N = off.size() - 1, n = bases.size() + N;
+    bfq_ctx *c = bfq_create(0, nullptr);
+    if (!c) { fprintf(stderr, "%s: %s\n", tool, bfq_create_error()); return 1; }
+    std::vector<uint8_t> bwt(n), qs(n);
+    std::vector<uint16_t> lcp(wantLcp ? n : 0);
+    int rc = bfq_build_ebwt(c, bases.data(), quals.data(), off.data(), N, term, bwt.data(), qs.data(),
+                            wantLcp ? lcp.data() : nullptr);
+    if (rc) { fprintf(stderr, "%s: %s\n", tool, bfq_last_error(c)); bfq_destroy(c); return 1; }
+    bfq_destroy(c);
+    bool ok = write_file(out + ".bwt", bwt.data(), n) && write_file(out + ".bwt.qs", qs.data(), n);
+    if (ok && wantLcp) {
+        std::string lp = out + "." + std::to_string(lbytes) + ".lcp";
+        if (lbytes == 2) ok = write_file(lp, lcp.data(), 2 * n);
+        else if (lbytes == 1) {
+            std::vector<uint8_t> l8(n);
+            for (uint64_t i = 0; i < n; i++) l8[i] = lcp[i] > 255 ? 255 : (uint8_t)lcp[i];
+            ok = write_file(lp, l8.data(), n);
+        } else {
+            std::vector<uint32_t> l32(lcp.begin(), lcp.end());
+            ok = write_file(lp, l32.data(), 4 * n);
+        }
+    }
+    if (!ok) { fprintf(stderr, "%s: cannot write outputs for %s\n", tool, out.c_str()); return 1; }
+    printf("%s (bfqzip_amd/gfx950): %llu reads, %llu eBWT symbols -> %s.bwt, %s.bwt.qs%s\n", tool, (unsigned long long)N,
+           (unsigned long long)n, out.c_str(), out.c_str(), wantLcp ? " (+lcp)" : "");
+    return 0;
+}
