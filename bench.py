@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=os.environ.get("BFQ_BENCH_WORKLOAD", "30Mx150"))
-    ap.add_argument("--sample-reads", type=int, default=100_000)
+    ap.add_argument("--sample-reads", type=int, default=0, help="reads in the CPU-baseline sample (0: about 40 Mbases)")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--M", type=int, default=2)
     ap.add_argument("--B", type=int, default=None)
@@ -100,6 +100,7 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
+    tstart = time.perf_counter()
     N, L = parse_workload(args.workload)
     B = args.B if args.B is not None else (1 if (N, L) == (30_000_000, 150) else 0)   # BASELINE.json configs[2]: B=1
     par = dict(k=16, m=5, v=ord(">"), f=40, t=20, M=args.M, B=B)                      # -m 5: what BFQzip.py passes
@@ -121,9 +122,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - tstart:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log(f"synthetic reads resident: {N}x{L}")
     st = None
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         st = step()
+        log(f"warmup step {i} done, workspace {eng.workspace_bytes() / 2**30:.1f} GiB")
     eng.prof_reset()
     barrier()
     t0 = time.perf_counter()
@@ -140,6 +147,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = eng.prof()
+    log(f"{args.steps} timed steps: {dt:.3f}s")
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -167,7 +175,7 @@ def main():
                "workspace_gib": round(eng.workspace_bytes() / 2**30, 2)}
         if world == 1 and not args.no_cpu:
             from oracle import orc
-            cb, (sb, sq, sr, sout) = cpu_baseline(api, orc, L, seed, min(args.sample_reads, N), par)
+            cb, (sb, sq, sr, sout) = cpu_baseline(api, orc, L, seed, min(args.sample_reads or max(1000, 40_000_000 // L), N), par)
             res["cpu_baseline"] = cb
             # the GPU path on the same sample must reproduce the CPU output byte for byte
             gb, gq, gst = eng.run_reads(sb, sq, sr)

@@ -373,13 +373,9 @@ extern "C" int bfq_count_reads(const uint8_t *h_bwt, uint64_t n, int term, uint6
 __global__ __launch_bounds__(256) void k_compare_bytes(const u8 *__restrict__ a, const u8 *__restrict__ b, u64 n,
                                                        DevCounters *cnt)
 {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && a[i] != b[i]) atomicAdd(&cnt->mismatch, 1ull);
-}
-__global__ __launch_bounds__(256) void k_widen_lens(const u32 *__restrict__ lens, u64 N, u64 *__restrict__ out)
-{
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) out[i] = lens[i];
+    bool bad = false;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) bad |= (a[i] != b[i]);
+    if (bad) atomicAdd(&cnt->mismatch, 1ull);
 }
 
 extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp,
@@ -441,7 +437,7 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
                 c->release(m2);
             }
             bfq_step1_device(c, rb, rq, d_roff, N, total, c->P.term, st);
-            KLAUNCH(c, K_MISC, 2.0 * (double)n, k_compare_bytes, ceil_div(n ? n : 1, 256), 256, (const u8 *)c->d_bwt,
+            KLAUNCH(c, K_MISC, 2.0 * (double)n, k_compare_bytes, bfq_grid(n, 256), 256, (const u8 *)c->d_bwt,
                     (const u8 *)in_bwt, n, c->d_cnt);
             HIP_CHECK(hipMemcpyAsync(c->d_qual, in_qs, n, hipMemcpyDeviceToDevice, c->stream));
             (void)m;   // rb/rq stay allocated below the step-1 arrays; the arena is reset per call

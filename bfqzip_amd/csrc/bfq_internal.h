@@ -106,6 +106,14 @@ struct bfq_ctx {
     } while (0)
 
 static inline u64 ceil_div(u64 a, u64 b) { return (a + b - 1) / b; }
+// HIP caps gridDim.x * blockDim.x below 2^32: every kernel is launched on at most
+// BFQ_MAX_GRID workgroups and strides over its work items.
+#define BFQ_MAX_GRID (1u << 19)
+static inline unsigned bfq_grid(u64 items, u64 perBlock)
+{
+    u64 b = ceil_div(items, perBlock);
+    return (unsigned)(b < 1 ? 1 : (b > BFQ_MAX_GRID ? BFQ_MAX_GRID : b));
+}
 
 // ---- stage entry points (each in its own .hip file) --------------------------------
 // scan: out[i] = sum(in[0..i)) ; T in {u8,u32,u64}; total (device u64) optional

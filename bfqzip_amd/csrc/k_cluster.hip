@@ -20,13 +20,13 @@
 
 __global__ __launch_bounds__(256) void k_lcp_flags(const u16 *__restrict__ lcp, u64 n, int K, u8 *__restrict__ in)
 {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    int l = (int)lcp[r];
-    bool thr = (r >= 1) && (l >= K);
-    bool mn = false;
-    if (r >= 1 && r + 2 <= n) mn = ((int)lcp[r - 1] > l) && ((int)lcp[r + 1] >= l);
-    in[r] = (thr && !mn) ? 1 : 0;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
+        int l = (int)lcp[r];
+        bool thr = (r >= 1) && (l >= K);
+        bool mn = false;
+        if (r >= 1 && r + 2 <= n) mn = ((int)lcp[r - 1] > l) && ((int)lcp[r + 1] >= l);
+        in[r] = (thr && !mn) ? 1 : 0;
+    }
 }
 
 struct ClStat { u32 clust, disc, amb, mod, alleq, bases, qs, modb; };
@@ -178,11 +178,12 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
     __shared__ u32 shst[8];
     if (threadIdx.x < 8) shst[threadIdx.x] = 0;
     __syncthreads();
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= 1 && r < a.n && a.in[r] && !a.in[r - 1]) {
-        u64 e = r;
-        while (e + 1 < a.n && a.in[e + 1]) e++;
-        process_cluster(a, r - 1, e, shst);
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < a.n; r += (u64)gridDim.x * blockDim.x) {
+        if (r >= 1 && a.in[r] && !a.in[r - 1]) {
+            u64 e = r;
+            while (e + 1 < a.n && a.in[e + 1]) e++;
+            process_cluster(a, r - 1, e, shst);
+        }
     }
     __syncthreads();
     if (threadIdx.x < 8 && shst[threadIdx.x]) atomicAdd(&a.cnt->stats[threadIdx.x], (u64)shst[threadIdx.x]);
@@ -191,7 +192,7 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a)
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
 {
     if (!n) return;
-    KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, ceil_div(n, 256), 256, lcp, n, K, in);
+    KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, bfq_grid(n, 256), 256, lcp, n, K, in);
 }
 
 void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, u8 *qual, const u8 *in, u64 n, u8 *modsym)
@@ -203,5 +204,5 @@ void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, u8 *qual, const
     a.powtab = c->d_powtab; a.qthr = c->d_qthr; a.qthrLo = c->qthrLo; a.qthrN = c->qthrN;
     a.cnt = c->d_cnt;
     HIP_CHECK(hipMemsetAsync(modsym, 0, n, c->stream));
-    KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, ceil_div(n, 256), 256, a);
+    KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, bfq_grid(n, 256), 256, a);
 }

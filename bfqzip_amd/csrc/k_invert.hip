@@ -12,25 +12,24 @@
 
 __global__ __launch_bounds__(256) void k_invert_count(RankIndex R, u64 N, u32 *__restrict__ lens, DevCounters *cnt)
 {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
-    u64 j = i, nx = 0;
-    u32 len = 0;
-    for (;;) {
-        u32 code = rank_step(R, j, &nx);
-        if (!code) break;
-        if (++len > BFQ_MAX_READ_LEN || nx >= R.n) { atomicAdd(&cnt->errInvert, 1ull); break; }
-        j = nx;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        u64 j = i, nx = 0;
+        u32 len = 0;
+        for (;;) {
+            u32 code = rank_step(R, j, &nx);
+            if (!code) break;
+            if (++len > BFQ_MAX_READ_LEN || nx >= R.n) { atomicAdd(&cnt->errInvert, 1ull); break; }
+            j = nx;
+        }
+        lens[i] = len;
     }
-    lens[i] = len;
 }
 
 __global__ __launch_bounds__(256) void k_invert(RankIndex R, const u8 *__restrict__ qual, const u8 *__restrict__ modsym,
                                                 u64 N, const u64 *__restrict__ roff, int B, u8 *__restrict__ out_bases,
                                                 u8 *__restrict__ out_quals, DevCounters *cnt)
 {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N) return;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
     u64 lo = roff[i], pos = roff[i + 1];
     u64 j = i, nx = 0;
     bool bad = false;
@@ -46,18 +45,19 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, const u8 *__restric
     }
     if (!bad && rank_code_at(R, j) != 0) bad = true;             // read longer than its slot
     if (bad) atomicAdd(&cnt->errInvert, 1ull);
+    }
 }
 
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens)
 {
     if (!N) return;
-    KLAUNCH(c, K_INVERT_COUNT, 128.0 * (double)(R.n - N), k_invert_count, ceil_div(N, 256), 256, R, N, lens, c->d_cnt);
+    KLAUNCH(c, K_INVERT_COUNT, 128.0 * (double)(R.n - N), k_invert_count, bfq_grid(N, 256), 256, R, N, lens, c->d_cnt);
 }
 
 void bfq_invert(bfq_ctx *c, const RankIndex &R, const u8 *qual, const u8 *modsym, u64 N, const u64 *d_roff,
                 u8 *out_bases, u8 *out_quals)
 {
     if (!N) return;
-    KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert, ceil_div(N, 256), 256, R, qual, modsym, N, d_roff,
+    KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert, bfq_grid(N, 256), 256, R, qual, modsym, N, d_roff,
             c->P.B, out_bases, out_quals, c->d_cnt);
 }

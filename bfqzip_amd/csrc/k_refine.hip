@@ -21,14 +21,14 @@
 __global__ __launch_bounds__(256) void k_seg_flags(const u64 *__restrict__ keys, u64 n, u8 *__restrict__ head,
                                                    u16 *__restrict__ lcp)
 {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    u64 k = keys[r];
-    if (r == 0) { head[0] = 1; lcp[0] = 0; return; }
-    u64 kp = keys[r - 1];
-    bool h = (k != kp) || bfq_key_has_term(k);
-    head[r] = h ? 1 : 0;
-    lcp[r] = h ? (u16)bfq_key_lcp(kp, k) : (u16)LCP_PENDING;
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
+        u64 k = keys[r];
+        if (r == 0) { head[0] = 1; lcp[0] = 0; continue; }
+        u64 kp = keys[r - 1];
+        bool h = (k != kp) || bfq_key_has_term(k);
+        head[r] = h ? 1 : 0;
+        lcp[r] = h ? (u16)bfq_key_lcp(kp, k) : (u16)LCP_PENDING;
+    }
 }
 
 // segment starts: head[r] && !head[r+1]  (segments of >= 2 rows)
@@ -72,15 +72,15 @@ __global__ __launch_bounds__(256) void k_refine_wave(const u64 *__restrict__ seg
                                                      DevCounters *cnt)
 {
     const u32 lane = bfq_lane();
-    u64 wid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wid >= nseg) return;                                  // wave-uniform
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 wid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wid < nseg; wid += nwaves) {   // wave-uniform
     u64 s = seglist[wid];
     u64 idx = s + 1 + lane;
     bool h = (idx >= n) ? true : (head[idx] != 0);
     u64 hm = __ballot(h);
     if (hm == 0) {                                            // more than 64 rows
         if (lane == 0) biglist[atomicAdd(&cnt->bigCount, 1ull)] = s;
-        return;
+        continue;
     }
     const int g = __builtin_ctzll(hm) + 1;                    // 2..64 rows
     const bool act = (int)lane < g;
@@ -121,6 +121,7 @@ __global__ __launch_bounds__(256) void k_refine_wave(const u64 *__restrict__ seg
         vals[s + lane] = v;
         if (lane > 0) lcp[s + lane] = (u16)mylcp;
     }
+    }
 }
 
 // ---- larger segments: one workgroup each, bitonic network in global memory -------
@@ -158,7 +159,9 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
                                                     const u64 *__restrict__ text3, u64 n)
 {
     __shared__ u64 shEnd;
-    const u64 s = biglist[blockIdx.x];
+    for (u64 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+    const u64 s = biglist[bi];
+    __syncthreads();
     if (threadIdx.x == 0) shEnd = ~0ull;
     __syncthreads();
     for (u64 base = s + 1;; base += 256) {         // first head after s = end of the segment
@@ -182,18 +185,19 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
     }
     for (u64 i = 1 + threadIdx.x; i < g; i += 256)
         lcp[s + i] = (u16)suffix_lcp(text3, bfq_val_pos(a[i - 1]), bfq_val_pos(a[i]));
+    }
 }
 
 // eBWT byte and permuted quality of every row, from the sort payload
 __global__ __launch_bounds__(256) void k_emit_bwt(const u64 *__restrict__ vals, u64 n, u32 termOut, u8 *__restrict__ bwt,
                                                   u8 *__restrict__ qs)
 {
-    u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n) return;
-    u64 v = vals[r];
-    u32 code = bfq_val_code(v);
-    bwt[r] = code ? bfq_code_sym(code) : (u8)termOut;
-    qs[r] = (u8)bfq_val_qual(v);
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
+        u64 v = vals[r];
+        u32 code = bfq_val_code(v);
+        bwt[r] = code ? bfq_code_sym(code) : (u8)termOut;
+        qs[r] = (u8)bfq_val_qual(v);
+    }
 }
 
 void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st)
@@ -201,7 +205,7 @@ void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n,
     if (!n) return;
     size_t m = c->mark();
     u8 *head = c->alloc<u8>(n + 64);
-    KLAUNCH(c, K_SEG_FLAGS, 19.0 * (double)n, k_seg_flags, ceil_div(n, 256), 256, keys, n, head, lcp);
+    KLAUNCH(c, K_SEG_FLAGS, 19.0 * (double)n, k_seg_flags, bfq_grid(n, 256), 256, keys, n, head, lcp);
     u64 nchunks = ceil_div(n, SG_CHUNK);
     u32 *counts = c->alloc<u32>(nchunks);
     u64 *bases = c->alloc<u64>(nchunks);
@@ -217,14 +221,14 @@ void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n,
         u64 *biglist = c->alloc<u64>(nseg);
         KLAUNCH(c, K_SEG_COMPACT, (double)n + 8.0 * (double)nseg, k_seg_write, nchunks, 256, (const u8 *)head, n,
                 (const u64 *)bases, seglist);
-        KLAUNCH(c, K_REFINE_WAVE, 26.0 * (double)n, k_refine_wave, ceil_div(nseg, 4), 256, (const u64 *)seglist, nseg,
+        KLAUNCH(c, K_REFINE_WAVE, 26.0 * (double)n, k_refine_wave, bfq_grid(nseg, 4), 256, (const u64 *)seglist, nseg,
                 vals, (const u8 *)head, lcp, text3, n, biglist, c->d_cnt);
         u64 nbig = 0;
         HIP_CHECK(hipMemcpyAsync(&nbig, &c->d_cnt->bigCount, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         c->sync();
         if (st) st->n_big_segments = nbig;
         if (nbig)
-            KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, nbig, 256, (const u64 *)biglist, nbig, vals, (const u8 *)head,
+            KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, bfq_grid(nbig, 1), 256, (const u64 *)biglist, nbig, vals, (const u8 *)head,
                     lcp, text3, n);
     }
     c->release(m);
@@ -233,5 +237,5 @@ void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n,
 void bfq_emit_bwt(bfq_ctx *c, const u64 *vals, u64 n, int termOut, u8 *bwt, u8 *qs)
 {
     if (!n) return;
-    KLAUNCH(c, K_EMIT, 10.0 * (double)n, k_emit_bwt, ceil_div(n, 256), 256, vals, n, (u32)(termOut & 0xFF), bwt, qs);
+    KLAUNCH(c, K_EMIT, 10.0 * (double)n, k_emit_bwt, bfq_grid(n, 256), 256, vals, n, (u32)(termOut & 0xFF), bwt, qs);
 }

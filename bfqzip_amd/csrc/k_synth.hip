@@ -5,8 +5,8 @@
 
 __global__ __launch_bounds__(256) void k_synth_lens(bfq_synth s, u32 *__restrict__ lens)
 {
-    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < s.N) lens[i] = bfq_synth_len(&s, i);
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < s.N; i += (u64)gridDim.x * blockDim.x)
+        lens[i] = bfq_synth_len(&s, i);
 }
 
 // one wave per read
@@ -33,7 +33,7 @@ void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, 
     if (!s->N) { HIP_CHECK(hipMemsetAsync(d_roff, 0, sizeof(u64), c->stream)); return; }
     size_t m = c->mark();
     u32 *lens = c->alloc<u32>(s->N);
-    KLAUNCH(c, K_SYNTH, 4.0 * (double)s->N, k_synth_lens, ceil_div(s->N, 256), 256, *s, lens);
+    KLAUNCH(c, K_SYNTH, 4.0 * (double)s->N, k_synth_lens, bfq_grid(s->N, 256), 256, *s, lens);
     bfq_exscan_u32(c, lens, d_roff, s->N, d_roff + s->N);
     u64 waves = s->N < (1u << 18) ? s->N : (1u << 18);
     KLAUNCH(c, K_SYNTH, 2.0 * (double)s->N * s->Lmax, k_synth_reads, ceil_div(waves, 4), 256, *s, (const u64 *)d_roff,

@@ -35,17 +35,17 @@ __global__ __launch_bounds__(256) void k_text_from_reads(const u8 *__restrict__ 
 // one thread per packed word: 21 codes -> 63 bits, first symbol in the top field
 __global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n, u64 *__restrict__ text3, u64 nwords)
 {
-    u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= nwords) return;
-    u64 p0 = w * BFQ_SYMS_PER_WORD;
-    u64 v = 0;
+    for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (u64)gridDim.x * blockDim.x) {
+        u64 p0 = w * BFQ_SYMS_PER_WORD;
+        u64 v = 0;
 #pragma unroll
-    for (int j = 0; j < BFQ_SYMS_PER_WORD; j++) {
-        u64 p = p0 + j;
-        u64 c = (p < n) ? (u64)T8[p] : 0ull;
-        v = (v << 3) | c;
+        for (int j = 0; j < BFQ_SYMS_PER_WORD; j++) {
+            u64 p = p0 + j;
+            u64 c = (p < n) ? (u64)T8[p] : 0ull;
+            v = (v << 3) | c;
+        }
+        text3[w] = v;
     }
-    text3[w] = v;
 }
 
 // one thread per suffix: masked 21-symbol key + payload (position, previous symbol, its quality)
@@ -53,15 +53,15 @@ __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, c
                                                     const u64 *__restrict__ text3, u64 n, u64 *__restrict__ keys,
                                                     u64 *__restrict__ vals)
 {
-    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    u32 pc = 0, pq = (u32)'#';
-    if (p > 0) {
-        pc = T8[p - 1];
-        if (pc) pq = Q8[p - 1];
+    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (u64)gridDim.x * blockDim.x) {
+        u32 pc = 0, pq = (u32)'#';
+        if (p > 0) {
+            pc = T8[p - 1];
+            if (pc) pq = Q8[p - 1];
+        }
+        keys[p] = bfq_key_at(text3, p);
+        vals[p] = bfq_pack_val(p, pc, pq);
     }
-    keys[p] = bfq_key_at(text3, p);
-    vals[p] = bfq_pack_val(p, pc, pq);
 }
 
 void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 n, u8 *T8,
@@ -73,12 +73,12 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
         KLAUNCH(c, K_TEXT, 4.0 * (double)(n - N), k_text_from_reads, blocks, 256, d_bases, d_quals, d_roff, N, T8, Q8,
                 c->d_cnt);
     }
-    KLAUNCH(c, K_PACK, (double)n + 8.0 * (double)nwords, k_pack3, ceil_div(nwords, 256), 256, (const u8 *)T8, n, text3,
+    KLAUNCH(c, K_PACK, (double)n + 8.0 * (double)nwords, k_pack3, bfq_grid(nwords, 256), 256, (const u8 *)T8, n, text3,
             nwords);
 }
 
 void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u64 *keys, u64 *vals)
 {
     if (!n) return;
-    KLAUNCH(c, K_KEYS, 18.5 * (double)n, k_build_keys, ceil_div(n, 256), 256, T8, Q8, text3, n, keys, vals);
+    KLAUNCH(c, K_KEYS, 18.5 * (double)n, k_build_keys, bfq_grid(n, 256), 256, T8, Q8, text3, n, keys, vals);
 }
