@@ -218,6 +218,7 @@ static void check_counters(bfq_ctx *c)
     if (h.errTooLong) throw BfqError{BFQ_E_TOO_LONG, "read longer than BFQ_MAX_READ_LEN"};
     if (h.errInvert) throw BfqError{BFQ_E_NOT_EBWT, "LF walk did not close: not an eBWT of a read collection"};
     if (h.mismatch) throw BfqError{BFQ_E_NOT_EBWT, "eBWT is not in #_i<#_j<A<C<G<N<T suffix order"};
+    if (h.errQual) throw BfqError{BFQ_E_ARG, "quality byte >= 128 (not FASTQ)"};
     if (h.errFreq3) throw BfqError{BFQ_E_FREQ3, "three frequent symbols in a cluster (bfq_int.cpp:505 assert); raise -f"};
 }
 static void fill_stats(bfq_ctx *c, bfq_stats *st)
@@ -276,12 +277,13 @@ static void steps234_device(bfq_ctx *c, const u64 *d_roff, u8 *d_out_bases, u8 *
 {
     u64 n = c->n, N = c->N;
     if (!n) return;
-    RankIndex R = bfq_rank_build(c, c->d_bwt, n, c->P.term);
+    if ((((uintptr_t)d_out_bases) | ((uintptr_t)d_out_quals)) & 7) throw BfqError{BFQ_E_ARG, "output buffers must be 8-byte aligned"};
+    RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term);
     u8 *in = c->alloc<u8>(n + 64);
-    u8 *modsym = c->alloc<u8>(n + 64);
+    u8 *modsym = c->alloc<u8>(n + 64);     // written only where a rank block carries the replaced flag
     bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
     bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n, modsym);
-    bfq_invert(c, R, c->d_qual, modsym, N, d_roff, d_out_bases, d_out_quals);
+    bfq_invert(c, R, modsym, N, d_roff, c->P.B, d_out_bases, d_out_quals);
 }
 
 extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_quals,
@@ -412,7 +414,7 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
             }
             HIP_CHECK(hipMemcpyAsync(c->d_lcp, lcp16.data(), 2 * n, hipMemcpyHostToDevice, c->stream));
             size_t m = c->mark();
-            RankIndex R0 = bfq_rank_build(c, in_bwt, n, c->P.term);
+            RankIndex R0 = bfq_rank_build(c, in_bwt, in_qs, n, c->P.term);
             bfq_invert_count(c, R0, N, lens);
             bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
             c->release(m);
@@ -423,7 +425,7 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
             u8 *rb = c->alloc<u8>(total + 64), *rq = c->alloc<u8>(total + 64);
             {
                 size_t m2 = c->mark();
-                RankIndex R0 = bfq_rank_build(c, in_bwt, n, c->P.term);
+                RankIndex R0 = bfq_rank_build(c, in_bwt, in_qs, n, c->P.term);
                 bfq_invert_count(c, R0, N, lens);
                 bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
                 u64 tot2 = 0;
@@ -431,9 +433,7 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
                 c->fetchCounters();
                 check_counters(c);
                 if (tot2 != total) throw BfqError{BFQ_E_NOT_EBWT, "LF walks do not cover the eBWT"};
-                int B = c->P.B; c->P.B = 0;
-                bfq_invert(c, R0, in_qs, nullptr, N, d_roff, rb, rq);
-                c->P.B = B;
+                bfq_invert(c, R0, nullptr, N, d_roff, 0, rb, rq);
                 c->release(m2);
             }
             bfq_step1_device(c, rb, rq, d_roff, N, total, c->P.term, st);

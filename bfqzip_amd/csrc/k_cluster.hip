@@ -33,7 +33,7 @@ struct ClStat { u32 clust, disc, amb, mod, alleq, bases, qs, modb; };
 
 struct ClusterArgs {
     RankIndex R;
-    const u8 *bwt; u8 *qual; const u8 *in; u8 *modsym; u64 n;
+    const u8 *bwt; const u8 *qual; const u8 *in; u8 *modsym; u64 n;
     int m, v, f, t, term, M, ext;
     const double *powtab;   // [256] pow(10,-((signed char)q-33)/10), host libm
     const double *qthr;     // [qthrN] decreasing: smallest x with round(-10*log10(x)) <= qthrLo+k
@@ -47,6 +47,20 @@ __device__ __forceinline__ int ord5(u8 c)   // bfq_int.cpp:106-110: A0 C1 G2 T3 
 }
 __device__ __forceinline__ u8 dna5(int i) { return (u8)((0x4E54474341ull >> (8 * i)) & 0xFF); }   // "ACGTN"
 
+// Edits go to the rank blocks the inversion reads (bfq_rank.h): the smoothed quality
+// replaces the block's quality byte, a replaced base sets bit 7 of it and records the
+// symbol in modsym[] (reference: QUAL[j]=..., rankbv_setbit + BWT_MOD.push_back,
+// bfq_int.cpp:386-391).  a.qual[] keeps the original permuted qualities (read only).
+__device__ __forceinline__ void set_qual(const ClusterArgs &a, u64 j, int newqs)
+{
+    a.R.blk[j >> 5].q[j & 31] = (u8)newqs & 0x7Fu;
+}
+__device__ __forceinline__ void set_mod(const ClusterArgs &a, u64 j, u8 sym)
+{
+    a.modsym[j] = sym;
+    a.R.blk[j >> 5].q[j & 31] = a.qual[j] | 0x80u;
+}
+
 // bfq_int.cpp:376-405 modBasesSmoothQS
 __device__ __forceinline__ void mod_smooth(const ClusterArgs &a, u64 start, u64 end, u8 newSymb, int newqs, u32 lowQS, ClStat &st)
 {
@@ -54,9 +68,9 @@ __device__ __forceinline__ void mod_smooth(const ClusterArgs &a, u64 start, u64 
     for (u64 j = start; j <= end; j++) {
         u8 b = a.bwt[j];
         if (b == TERM) continue;
-        if (b != newSymb && !((lowQS >> ord5(b)) & 1u)) { a.modsym[j] = newSymb; st.modb++; }
-        else if (b == newSymb) { a.qual[j] = (u8)newqs; st.qs++; }
-        else if (newqs < (int)(signed char)a.qual[j]) { a.qual[j] = (u8)newqs; st.qs++; }
+        if (b != newSymb && !((lowQS >> ord5(b)) & 1u)) { set_mod(a, j, newSymb); st.modb++; }
+        else if (b == newSymb) { set_qual(a, j, newqs); st.qs++; }
+        else if (newqs < (int)(signed char)a.qual[j]) { set_qual(a, j, newqs); st.qs++; }
     }
 }
 
@@ -145,12 +159,12 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
             if (b == TERM) continue;
             if (b != Freq[0] && b != Freq[1] && !((lowQS >> ord5(b)) & 1u)) {
                 u8 ch = a.bwt[rank_lf(a.R, j, bfq_base_code(b))];
-                if (ch == symbPrec[0]) { a.modsym[j] = Freq[0]; st.modb++; }
-                else if (ch == symbPrec[1]) { a.modsym[j] = Freq[1]; st.modb++; }
+                if (ch == symbPrec[0]) { set_mod(a, j, Freq[0]); st.modb++; }
+                else if (ch == symbPrec[1]) { set_mod(a, j, Freq[1]); st.modb++; }
             } else if (b == Freq[0] || b == Freq[1]) {
-                a.qual[j] = (u8)newqs; st.qs++;
+                set_qual(a, j, newqs); st.qs++;
             } else if (newqs < (int)(signed char)a.qual[j]) {
-                a.qual[j] = (u8)newqs; st.qs++;
+                set_qual(a, j, newqs); st.qs++;
             }
         }
     } else {
@@ -195,7 +209,7 @@ void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
     KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, bfq_grid(n, 256), 256, lcp, n, K, in);
 }
 
-void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, u8 *qual, const u8 *in, u64 n, u8 *modsym)
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, u8 *modsym)
 {
     if (!n) return;
     ClusterArgs a;
@@ -203,6 +217,5 @@ void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, u8 *qual, const
     a.m = c->P.m; a.v = c->P.v; a.f = c->P.f; a.t = c->P.t; a.term = c->P.term & 0xFF; a.M = c->P.M; a.ext = c->P.ext;
     a.powtab = c->d_powtab; a.qthr = c->d_qthr; a.qthrLo = c->qthrLo; a.qthrN = c->qthrN;
     a.cnt = c->d_cnt;
-    HIP_CHECK(hipMemsetAsync(modsym, 0, n, c->stream));
     KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, bfq_grid(n, 256), 256, a);
 }

@@ -4,8 +4,10 @@
 // per read (the lock-step formulation of bfq_ext's BCRdecode, decode.cpp:499-686):
 // read i starts at row i; each step emits (replacement or eBWT symbol, quality
 // -- Illumina-binned when B=1, bfq_int.cpp:784-786) and moves to LF(row) until
-// the terminator row.  One step = one 128-byte rank block + one quality byte +
-// one replacement byte; N walks in flight hide the dependent-load latency.
+// the terminator row.  One step = ONE 64-byte rank block (counters, bit planes,
+// quality byte, replaced flag: bfq_rank.h); the replacement symbol is fetched from
+// modsym[] only for the ~1% flagged rows.  N walks in flight hide the dependent-
+// load latency; output bytes are collected in registers and stored 8 at a time.
 #include "bfq_internal.h"
 #include "bfq_device.h"
 #include "bfq_rank.h"
@@ -13,11 +15,13 @@
 __global__ __launch_bounds__(256) void k_invert_count(RankIndex R, u64 N, u32 *__restrict__ lens, DevCounters *cnt)
 {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
-        u64 j = i, nx = 0;
+        u64 j = i;
         u32 len = 0;
         for (;;) {
-            u32 code = rank_step(R, j, &nx);
+            RankHdr h = rank_load_hdr(R, j);
+            u32 code = rank_hdr_code(h, j);
             if (!code) break;
+            u64 nx = rank_hdr_lf(R, h, j, code);
             if (++len > BFQ_MAX_READ_LEN || nx >= R.n) { atomicAdd(&cnt->errInvert, 1ull); break; }
             j = nx;
         }
@@ -25,39 +29,67 @@ __global__ __launch_bounds__(256) void k_invert_count(RankIndex R, u64 N, u32 *_
     }
 }
 
-__global__ __launch_bounds__(256) void k_invert(RankIndex R, const u8 *__restrict__ qual, const u8 *__restrict__ modsym,
-                                                u64 N, const u64 *__restrict__ roff, int B, u8 *__restrict__ out_bases,
+__device__ __forceinline__ void flush_bytes(u8 *dst, u64 from, u64 to, u64 acc)   // bytes [from,to) of the 8-byte word at from&~7
+{
+    for (u64 p = from; p < to; p++) dst[p] = (u8)(acc >> (8 * (p & 7)));
+}
+
+__global__ __launch_bounds__(256) void k_invert(RankIndex R, const u8 *__restrict__ modsym, u64 N,
+                                                const u64 *__restrict__ roff, int B, u8 *__restrict__ out_bases,
                                                 u8 *__restrict__ out_quals, DevCounters *cnt)
 {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
-    u64 lo = roff[i], pos = roff[i + 1];
-    u64 j = i, nx = 0;
-    bool bad = false;
-    while (pos > lo) {
-        u32 code = rank_step(R, j, &nx);
-        if (!code || nx >= R.n) { bad = true; break; }           // walk ended before the read did
-        u8 ms = modsym ? modsym[j] : (u8)0;
-        u32 q = qual[j];
-        --pos;
-        out_bases[pos] = ms ? ms : bfq_code_sym(code);
-        out_quals[pos] = (u8)(B ? bfq_bin8(q) : q);
-        j = nx;
-    }
-    if (!bad && rank_code_at(R, j) != 0) bad = true;             // read longer than its slot
-    if (bad) atomicAdd(&cnt->errInvert, 1ull);
+        const u64 lo = roff[i], end = roff[i + 1];
+        u64 pos = end, j = i;
+        u64 accb = 0, accq = 0;
+        bool bad = false;
+        while (pos > lo) {
+            RankHdr h = rank_load_hdr(R, j);
+            u32 q = R.blk[j >> 5].q[j & 31];
+            u32 code = rank_hdr_code(h, j);
+            if (!code) { bad = true; break; }                        // walk ended before the read did
+            u64 nx = rank_hdr_lf(R, h, j, code);
+            if (nx >= R.n) { bad = true; break; }
+            u32 sym = bfq_code_sym(code);
+            if (q & 0x80u) { sym = modsym[j]; q &= 0x7Fu; }
+            if (B) q = bfq_bin8(q);
+            --pos;
+            u32 sh = (u32)(pos & 7) * 8;
+            accb |= (u64)sym << sh;
+            accq |= (u64)q << sh;
+            if ((pos & 7) == 0) {                                    // word [pos,pos+8) is complete or clipped by `end`
+                if (pos + 8 <= end) {
+                    *(u64 *)(out_bases + pos) = accb;
+                    *(u64 *)(out_quals + pos) = accq;
+                } else {
+                    flush_bytes(out_bases, pos, end, accb);
+                    flush_bytes(out_quals, pos, end, accq);
+                }
+                accb = 0; accq = 0;
+            }
+            j = nx;
+        }
+        if (!bad && (lo & 7)) {                                      // leading partial word [lo, min(end, align_up(lo)))
+            u64 hi = (lo + 7) & ~7ull;
+            if (hi > end) hi = end;
+            flush_bytes(out_bases, lo, hi, accb);
+            flush_bytes(out_quals, lo, hi, accq);
+        }
+        if (!bad && rank_code_at(R, j) != 0) bad = true;             // read longer than its slot
+        if (bad) atomicAdd(&cnt->errInvert, 1ull);
     }
 }
 
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens)
 {
     if (!N) return;
-    KLAUNCH(c, K_INVERT_COUNT, 128.0 * (double)(R.n - N), k_invert_count, bfq_grid(N, 256), 256, R, N, lens, c->d_cnt);
+    KLAUNCH(c, K_INVERT_COUNT, 64.0 * (double)(R.n - N), k_invert_count, bfq_grid(N, 256), 256, R, N, lens, c->d_cnt);
 }
 
-void bfq_invert(bfq_ctx *c, const RankIndex &R, const u8 *qual, const u8 *modsym, u64 N, const u64 *d_roff,
-                u8 *out_bases, u8 *out_quals)
+void bfq_invert(bfq_ctx *c, const RankIndex &R, const u8 *modsym, u64 N, const u64 *d_roff, int B, u8 *out_bases,
+                u8 *out_quals)
 {
     if (!N) return;
-    KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert, bfq_grid(N, 256), 256, R, qual, modsym, N, d_roff,
-            c->P.B, out_bases, out_quals, c->d_cnt);
+    KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert, bfq_grid(N, 256), 256, R, modsym, N, d_roff, B, out_bases,
+            out_quals, c->d_cnt);
 }
