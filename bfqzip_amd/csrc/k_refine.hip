@@ -5,8 +5,9 @@
 // complete suffix: equal such keys are identical suffixes, already in read order
 // (stable sort, #_i < #_j for i < j), so they are final.  All other segments of
 // >= 2 rows are refined on the following 21-symbol words of the text:
-//   k_refine_wave : one wavefront per segment of <= 64 rows, all rounds in
-//                   registers (rank-by-counting + ds_permute), LCP as a by-product
+//   k_refine_wave : segments of <= 64 rows, several packed into one wavefront (one row per
+//                   lane), all rounds in registers (stable rank by counting over lane
+//                   offsets + ds_permute), next word prefetched, LCP as a by-product
 //   k_refine_big  : one workgroup per larger segment, bitonic network over the
 //                   rows in global memory with a full suffix comparator
 // LCP convention: common prefix counted on bases only, terminators never match
@@ -49,78 +50,136 @@ __global__ __launch_bounds__(256) void k_seg_count(const u8 *__restrict__ head, 
     if (threadIdx.x == 0) counts[blockIdx.x] = tot;
 }
 
+// Writes one entry per segment of >= 2 rows: start row (40 bits) | size << 40, size = 2..64,
+// or 0 when the segment is longer than a wavefront.  Sizes come from a head-bit mask of the
+// chunk (+128 rows of look-ahead) kept in LDS.
 __global__ __launch_bounds__(256) void k_seg_write(const u8 *__restrict__ head, u64 n, const u64 *__restrict__ blockBase,
                                                    u64 *__restrict__ seglist)
 {
     __shared__ u32 sh[4];
+    __shared__ u64 hb[SG_CHUNK / 64 + 2];
+    const u32 lane = bfq_lane(), w = threadIdx.x >> 6;
     u64 base = (u64)blockIdx.x * SG_CHUNK;
+    for (u32 g = w; g < SG_CHUNK / 64 + 2; g += 4) {
+        u64 r = base + (u64)g * 64 + lane;
+        bool h = (r >= n) ? true : (head[r] != 0);          // rows past the end close the last segment
+        u64 m = __ballot(h);
+        if (lane == 0) hb[g] = m;
+    }
+    __syncthreads();
     u64 out = blockBase[blockIdx.x];
-    for (int k = 0; k < SG_CHUNK / 256; k++) {           // chunk order = row order
-        u64 r = base + (u64)k * 256 + threadIdx.x;
-        bool s = seg_start(head, r, n);
+    for (int k = 0; k < SG_CHUNK / 256; k++) {               // chunk order = row order
+        u32 li = k * 256 + threadIdx.x;
+        u64 r = base + li;
+        bool s = (r + 1 < n) && ((hb[li >> 6] >> (li & 63)) & 1ull) && !((hb[(li + 1) >> 6] >> ((li + 1) & 63)) & 1ull);
+        u32 size = 0;
+        if (s) {
+            u32 idx = li + 1;
+            u64 wd = hb[idx >> 6] >> (idx & 63);
+            u32 nxt;
+            if (wd) nxt = idx + (u32)__builtin_ctzll(wd);
+            else {
+                u64 w2 = hb[(idx >> 6) + 1];
+                nxt = w2 ? (((idx >> 6) + 1) << 6) + (u32)__builtin_ctzll(w2) : 0xFFFFu;
+            }
+            size = nxt - li;
+            if (size > 64) size = 0;                         // handled by k_refine_big
+        }
         u32 tot;
         u32 ex = bfq_block_exscan32(s ? 1u : 0u, sh, &tot);
-        if (s) seglist[out + ex] = r;
+        if (s) seglist[out + ex] = r | ((u64)size << 40);
         out += tot;
     }
 }
 
-// ---- one wavefront per segment of <= 64 rows --------------------------------------
+__device__ __forceinline__ u32 bfq_wave_max32(u32 v)
+{
+    u32 lane = bfq_lane();
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        u32 o = (u32)__builtin_amdgcn_ds_bpermute((int)((lane ^ d) << 2), (int)v);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+// ---- segments of <= 64 rows: a wavefront takes 64 list entries, packs as many segments as
+// fit into its 64 lanes (one row per lane) and refines them together, round by round:
+//   fetch the next 21-symbol word of every open row (prefetched one round ahead),
+//   stable rank inside each sub-segment by counting over lane offsets (ds_bpermute),
+//   one ds_permute of the payload, new sub-segment heads and their LCP from the words.
 __global__ __launch_bounds__(256) void k_refine_wave(const u64 *__restrict__ seglist, u64 nseg, u64 *__restrict__ vals,
-                                                     const u8 *__restrict__ head, u16 *__restrict__ lcp,
-                                                     const u64 *__restrict__ text3, u64 n, u64 *__restrict__ biglist,
-                                                     DevCounters *cnt)
+                                                     u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
+                                                     u64 *__restrict__ biglist, DevCounters *cnt)
 {
     const u32 lane = bfq_lane();
+    const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 wid = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; wid < nseg; wid += nwaves) {   // wave-uniform
-    u64 s = seglist[wid];
-    u64 idx = s + 1 + lane;
-    bool h = (idx >= n) ? true : (head[idx] != 0);
-    u64 hm = __ballot(h);
-    if (hm == 0) {                                            // more than 64 rows
-        if (lane == 0) biglist[atomicAdd(&cnt->bigCount, 1ull)] = s;
-        continue;
-    }
-    const int g = __builtin_ctzll(hm) + 1;                    // 2..64 rows
-    const bool act = (int)lane < g;
-    u64 v = act ? vals[s + lane] : 0ull;
-    u64 p = bfq_val_pos(v);
-    int sublo = 0;                                            // first lane of my sub-segment
-    u32 mylcp = LCP_PENDING;                                  // positional: LCP(row s+lane-1, row s+lane)
-    u64 unres = (g == 64) ? ~0ull : ((1ull << g) - 1ull);     // lanes whose order is still open
-    u32 depth = BFQ_SYMS_PER_WORD;
-    while (unres) {
-        const bool un = (unres >> lane) & 1ull;
-        u64 W = un ? bfq_key_at(text3, p + depth) : 0ull;
-        // rank inside the sub-segment by (W, position)
-        int c = 0;
-        for (int y = 0; y < g; y++) {
-            if (!((unres >> y) & 1ull)) continue;             // uniform
-            u64 Wy = bfq_readlane64(W, y);
-            u64 py = bfq_readlane64(p, y);
-            int sy = __builtin_amdgcn_readlane(sublo, y);
-            if (un && sy == sublo && (Wy < W || (Wy == W && py < p))) c++;
+    const u64 nbatch = (nseg + 63) >> 6;
+    for (u64 batch = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; batch < nbatch; batch += nwaves) {
+        u64 idx = batch * 64 + lane;
+        u64 ent = (idx < nseg) ? seglist[idx] : 0ull;
+        u64 segStart = ent & BFQ_POS_MASK;
+        u32 segSize = (idx < nseg) ? (u32)(ent >> 40) & 0x7Fu : 0u;
+        if (idx < nseg && segSize == 0) biglist[atomicAdd(&cnt->bigCount, 1ull)] = segStart;
+        u32 incl = bfq_wave_incscan32(segSize);
+        u32 excl = incl - segSize;
+        u32 done = 0;
+        while (done < 64) {
+            u32 base = (u32)__builtin_amdgcn_readlane((int)excl, (int)done);
+            u64 take = __ballot(lane >= done && incl - base <= 64u);
+            u32 ntake = (u32)__popcll(take);                                    // >= 1
+            u32 rows = (u32)__builtin_amdgcn_readlane((int)incl, (int)(done + ntake - 1)) - base;
+            if (rows == 0) { done += ntake; continue; }
+            // rows -> lanes
+            u64 myRow = 0;
+            int sublo = 0, subhi = 0, seglo = 0;
+            for (u32 t = 0; t < ntake; t++) {
+                int k = (int)(done + t);
+                u32 sz = (u32)__builtin_amdgcn_readlane((int)segSize, k);
+                if (!sz) continue;                                               // uniform
+                int hp = (int)((u32)__builtin_amdgcn_readlane((int)excl, k) - base);
+                u64 st = bfq_readlane64(segStart, k);
+                if ((int)lane >= hp && (int)lane < hp + (int)sz) { myRow = st + (u64)((int)lane - hp); sublo = hp; subhi = hp + (int)sz; seglo = hp; }
+            }
+            const bool act = lane < rows;
+            u64 v = act ? vals[myRow] : 0ull;
+            u32 mylcp = LCP_PENDING;                                            // positional: LCP(row-1,row)
+            u64 unres = __ballot(act);
+            u32 depth = BFQ_SYMS_PER_WORD;
+            u64 Wn = act ? bfq_key_at(text3, bfq_val_pos(v) + depth) : 0ull;
+            while (unres) {
+                const bool un = (unres >> lane) & 1ull;
+                u64 W = Wn;
+                Wn = (un && !bfq_key_has_term(W)) ? bfq_key_at(text3, bfq_val_pos(v) + depth + BFQ_SYMS_PER_WORD) : 0ull;
+                u32 maxsz = bfq_wave_max32(un ? (u32)(subhi - sublo) : 0u);
+                int c = 0;
+                for (u32 d = 1; d < maxsz; d++) {
+                    int up = (int)lane + (int)d, dn = (int)lane - (int)d;
+                    u64 Wu = bfq_bpermute64(W, up), Wd = bfq_bpermute64(W, dn);
+                    if (un && up < subhi && Wu < W) c++;
+                    if (un && dn >= sublo && Wd <= W) c++;
+                }
+                int np = un ? sublo + c : (int)lane;
+                v = bfq_permute64(v, np);
+                W = bfq_permute64(W, np);
+                Wn = bfq_permute64(Wn, np);
+                u64 Wprev = bfq_bpermute64(W, (int)lane - 1);
+                bool newhead = un && ((int)lane == sublo || W != Wprev || bfq_key_has_term(W));
+                if (un && (int)lane != sublo && newhead) mylcp = depth + (u32)bfq_key_lcp(Wprev, W);
+                u64 heads = __ballot(newhead || !un);
+                sublo = 63 - __clzll((long long)(heads & le));
+                u64 above = heads & ~le;
+                subhi = above ? __builtin_ctzll(above) : 64;
+                unres = __ballot(un && (subhi - sublo > 1));
+                depth += BFQ_SYMS_PER_WORD;
+            }
+            if (act) {
+                vals[myRow] = v;
+                if ((int)lane != seglo) lcp[myRow] = (u16)mylcp;
+            }
+            done += ntake;
         }
-        int np = un ? sublo + c : (int)lane;
-        v = bfq_permute64(v, np);
-        p = bfq_permute64(p, np);
-        W = bfq_permute64(W, np);
-        u64 Wprev = bfq_bpermute64(W, (int)lane - 1);
-        bool newhead = un && ((int)lane == sublo || W != Wprev || bfq_key_has_term(W));
-        if (un && (int)lane != sublo && newhead) mylcp = depth + (u32)bfq_key_lcp(Wprev, W);
-        u64 heads = __ballot(newhead || !un);
-        u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-        sublo = 63 - __clzll((long long)(heads & le));
-        u64 above = heads & ~le;
-        int subhi = above ? __builtin_ctzll(above) : 64;
-        unres = __ballot(un && (subhi - sublo > 1));
-        depth += BFQ_SYMS_PER_WORD;
-    }
-    if (act) {
-        vals[s + lane] = v;
-        if (lane > 0) lcp[s + lane] = (u16)mylcp;
-    }
     }
 }
 
@@ -221,8 +280,8 @@ void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n,
         u64 *biglist = c->alloc<u64>(nseg);
         KLAUNCH(c, K_SEG_COMPACT, (double)n + 8.0 * (double)nseg, k_seg_write, nchunks, 256, (const u8 *)head, n,
                 (const u64 *)bases, seglist);
-        KLAUNCH(c, K_REFINE_WAVE, 26.0 * (double)n, k_refine_wave, bfq_grid(nseg, 4), 256, (const u64 *)seglist, nseg,
-                vals, (const u8 *)head, lcp, text3, n, biglist, c->d_cnt);
+        KLAUNCH(c, K_REFINE_WAVE, 26.0 * (double)n, k_refine_wave, bfq_grid(ceil_div(nseg, 64), 4), 256,
+                (const u64 *)seglist, nseg, vals, lcp, text3, n, biglist, c->d_cnt);
         u64 nbig = 0;
         HIP_CHECK(hipMemcpyAsync(&nbig, &c->d_cnt->bigCount, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         c->sync();
