@@ -38,7 +38,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *__restrict
     hist[(u64)d * nblocks + blockIdx.x] = wh[0][d] + wh[1][d] + wh[2][d] + wh[3][d];
 }
 
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const u64 *__restrict__ kin, const u64 *__restrict__ vin,
+__global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(const u64 *__restrict__ kin, const u64 *__restrict__ vin,
                                                               u64 *__restrict__ kout, u64 *__restrict__ vout, u64 n,
                                                               int shift, const u64 *__restrict__ blockOff, u64 nblocks)
 {
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const u64 *__restr
 
         // tile order = (wave, round, lane): wave w owns slots [w*1024, w*1024+1024)
         u64 k[RS_ROUNDS];
-        u32 rk[RS_ROUNDS];
+        u32 pk[RS_ROUNDS];                                       // digit << 16 | rank, later digit << 16 | tile slot
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
             u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const u64 *__restr
             }
             u32 before = (u32)__popcll(peers & ltmask);
             u32 c0 = wcnt[w][d];
-            rk[r] = c0 + before;
+            pk[r] = (d << 16) | (c0 + before);
             __builtin_amdgcn_wave_barrier();
             if (before == 0) wcnt[w][d] = c0 + (u32)__popcll(peers);
             __builtin_amdgcn_wave_barrier();
@@ -95,35 +95,39 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(const u64 *__restr
         lstart[tid] = ls;
         __syncthreads();
 
-        u32 pos[RS_ROUNDS];
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
-            u32 d = (u32)(k[r] >> shift) & 255u;
-            pos[r] = lstart[d] + wcnt[w][d] + rk[r];
-            stage[pos[r]] = k[r];
+            u32 d = pk[r] >> 16;
+            u32 p = lstart[d] + wcnt[w][d] + (pk[r] & 0xFFFFu);
+            pk[r] = (d << 16) | p;
+            stage[p] = k[r];
+        }
+        // payloads are requested now so that their latency overlaps the key write-out
+        u64 v[RS_ROUNDS];
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; r++) {
+            u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
+            v[r] = (slot < cnt) ? vin[tbase + slot] : 0ull;
         }
         __syncthreads();
-
-        u64 dst[RS_ROUNDS];
 #pragma unroll
         for (int q = 0; q < RS_ROUNDS; q++) {
             u32 j = q * RS_THREADS + tid;
             u64 key = stage[j];
             u32 d = (u32)(key >> shift) & 255u;
-            dst[q] = gbase[d] + (u64)(j - lstart[d]);
-            if (j < cnt) kout[dst[q]] = key;
+            if (j < cnt) kout[gbase[d] + (u64)(j - lstart[d])] = key;
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RS_ROUNDS; r++) {
-            u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
-            stage[pos[r]] = (slot < cnt) ? vin[tbase + slot] : 0ull;
-        }
+        for (int r = 0; r < RS_ROUNDS; r++)                      // the payload's free top byte carries the digit
+            stage[pk[r] & 0xFFFFu] = v[r] | ((u64)(pk[r] >> 16) << 56);
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < RS_ROUNDS; q++) {
             u32 j = q * RS_THREADS + tid;
-            if (j < cnt) vout[dst[q]] = stage[j];
+            u64 x = stage[j];
+            u32 d = (u32)(x >> 56);
+            if (j < cnt) vout[gbase[d] + (u64)(j - lstart[d])] = x & 0x00FFFFFFFFFFFFFFull;
         }
         __syncthreads();
         gbase[tid] += tot;
