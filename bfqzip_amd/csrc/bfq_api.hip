@@ -14,7 +14,7 @@
 
 const char *const BFQ_KERNEL_NAMES[K_NUM] = {
     "k_text_from_reads", "k_pack3", "k_build_keys", "k_radix_hist", "k_scan", "k_radix_scatter", "k_seg_flags",
-    "k_seg_compact", "k_refine_wave", "k_refine_big", "k_emit_bwt", "k_rank_build", "k_rank_final", "k_lcp_flags",
+    "k_seg_compact", "k_refine_wave", "k_refine_big", "k_emit_bwt", "k_lf_count", "k_lf_build", "k_lcp_flags",
     "k_cluster_compact", "k_cluster", "k_invert_count", "k_invert", "k_synth", "misc"};
 
 static thread_local std::string g_createErr;
@@ -218,7 +218,6 @@ static void check_counters(bfq_ctx *c)
     if (h.errTooLong) throw BfqError{BFQ_E_TOO_LONG, "read longer than BFQ_MAX_READ_LEN"};
     if (h.errInvert) throw BfqError{BFQ_E_NOT_EBWT, "LF walk did not close: not an eBWT of a read collection"};
     if (h.mismatch) throw BfqError{BFQ_E_NOT_EBWT, "eBWT is not in #_i<#_j<A<C<G<N<T suffix order"};
-    if (h.errQual) throw BfqError{BFQ_E_ARG, "quality byte >= 128 (not FASTQ)"};
     if (h.errFreq3) throw BfqError{BFQ_E_FREQ3, "three frequent symbols in a cluster (bfq_int.cpp:505 assert); raise -f"};
 }
 static void fill_stats(bfq_ctx *c, bfq_stats *st)
@@ -280,10 +279,9 @@ static void steps234_device(bfq_ctx *c, const u64 *d_roff, u8 *d_out_bases, u8 *
     if ((((uintptr_t)d_out_bases) | ((uintptr_t)d_out_quals)) & 7) throw BfqError{BFQ_E_ARG, "output buffers must be 8-byte aligned"};
     RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term);
     u8 *in = c->alloc<u8>(n + 64);
-    u8 *modsym = c->alloc<u8>(n + 64);     // written only where a rank block carries the replaced flag
     bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
-    bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n, modsym);
-    bfq_invert(c, R, modsym, N, d_roff, c->P.B, d_out_bases, d_out_quals);
+    bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n);
+    bfq_invert(c, R, N, d_roff, c->P.B, d_out_bases, d_out_quals);
 }
 
 extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_quals,
@@ -433,7 +431,7 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
                 c->fetchCounters();
                 check_counters(c);
                 if (tot2 != total) throw BfqError{BFQ_E_NOT_EBWT, "LF walks do not cover the eBWT"};
-                bfq_invert(c, R0, nullptr, N, d_roff, 0, rb, rq);
+                bfq_invert(c, R0, N, d_roff, 0, rb, rq);
                 c->release(m2);
             }
             bfq_step1_device(c, rb, rq, d_roff, N, total, c->P.term, st);

@@ -40,18 +40,13 @@ struct DevCounters {
     u64 errTooLong;      // >0: read longer than BFQ_MAX_READ_LEN
     u64 tot[6];          // symbol totals of the eBWT: # A C G N T
     u64 mismatch;        // >0: rebuilt eBWT differs from the given one
-    u64 errQual;         // >0: quality byte >= 128 (bit 7 is the replaced-base flag)
-    u64 pad[10];
+    u64 pad[11];
 };
 
-// rank structure over the eBWT: 32 rows per 64-byte block (layout: bfq_rank.h)
-struct RankBlock { u32 cnt[4]; u32 pl[3]; u32 cntN; u8 q[32]; };
-
+// the tabulated rank queries: one u64 per eBWT row (layout: bfq_rank.h)
 struct RankIndex {
-    RankBlock *blk;         // [n/32 + 1]
-    const u64 *scanned;     // [6][ngroups] occurrences of each code before every 256-row group
-    const u64 *F;           // device: F[6] in order # A C G N T (dna_bwt_n.hpp:46-61)
-    u64 n, ngroups;
+    u64 *lfq;               // [n]
+    u64 n;
 };
 
 struct bfq_ctx {
@@ -136,10 +131,9 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
 // steps 2-4 pieces
 RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int term);
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in);
-void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, u8 *modsym);
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n);
 // LF walks: lengths only, then emission at given offsets
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);
-void bfq_invert(bfq_ctx *c, const RankIndex &R, const u8 *modsym, u64 N, const u64 *d_roff, int B,
-                u8 *out_bases, u8 *out_quals);
+void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals);
 
 void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, u64 *d_roff);

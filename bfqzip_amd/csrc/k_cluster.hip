@@ -33,7 +33,7 @@ struct ClStat { u32 clust, disc, amb, mod, alleq, bases, qs, modb; };
 
 struct ClusterArgs {
     RankIndex R;
-    const u8 *bwt; const u8 *qual; const u8 *in; u8 *modsym; u64 n;
+    const u8 *bwt; const u8 *qual; const u8 *in; u64 n;
     int m, v, f, t, term, M, ext;
     const double *powtab;   // [256] pow(10,-((signed char)q-33)/10), host libm
     const double *qthr;     // [qthrN] decreasing: smallest x with round(-10*log10(x)) <= qthrLo+k
@@ -47,18 +47,17 @@ __device__ __forceinline__ int ord5(u8 c)   // bfq_int.cpp:106-110: A0 C1 G2 T3 
 }
 __device__ __forceinline__ u8 dna5(int i) { return (u8)((0x4E54474341ull >> (8 * i)) & 0xFF); }   // "ACGTN"
 
-// Edits go to the rank blocks the inversion reads (bfq_rank.h): the smoothed quality
-// replaces the block's quality byte, a replaced base sets bit 7 of it and records the
-// symbol in modsym[] (reference: QUAL[j]=..., rankbv_setbit + BWT_MOD.push_back,
-// bfq_int.cpp:386-391).  a.qual[] keeps the original permuted qualities (read only).
+// Edits go to the LF-table entries the inversion reads (bfq_rank.h): the smoothed quality
+// replaces the entry's quality byte, a replaced base sets the flag and the replacement
+// code (reference: QUAL[j]=..., rankbv_setbit + BWT_MOD.push_back, bfq_int.cpp:386-391).
+// a.qual[] keeps the original permuted qualities (read only).
 __device__ __forceinline__ void set_qual(const ClusterArgs &a, u64 j, int newqs)
 {
-    a.R.blk[j >> 5].q[j & 31] = (u8)newqs & 0x7Fu;
+    lfq_set_qual(a.R.lfq, j, (u32)newqs & 0xFFu);
 }
 __device__ __forceinline__ void set_mod(const ClusterArgs &a, u64 j, u8 sym)
 {
-    a.modsym[j] = sym;
-    a.R.blk[j >> 5].q[j & 31] = a.qual[j] | 0x80u;
+    lfq_set_repl(a.R.lfq, j, bfq_base_code(a.bwt[j]), bfq_base_code(sym));
 }
 
 // bfq_int.cpp:376-405 modBasesSmoothQS
@@ -148,7 +147,7 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
         u8 b = a.bwt[j];
         int w = (b == Freq[0]) ? 0 : ((b == Freq[1]) ? 1 : -1);
         if (w < 0) continue;
-        u64 nx = rank_lf(a.R, j, bfq_base_code(b));
+        u64 nx = lfq_next(a.R.lfq[j]);
         u8 ch = a.bwt[nx];
         if (ch != TERM && ch != 'N') { fr[w] |= 1u << ord5(ch); symbPrec[w] = ch; }
     }
@@ -158,7 +157,7 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
             u8 b = a.bwt[j];
             if (b == TERM) continue;
             if (b != Freq[0] && b != Freq[1] && !((lowQS >> ord5(b)) & 1u)) {
-                u8 ch = a.bwt[rank_lf(a.R, j, bfq_base_code(b))];
+                u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
                 if (ch == symbPrec[0]) { set_mod(a, j, Freq[0]); st.modb++; }
                 else if (ch == symbPrec[1]) { set_mod(a, j, Freq[1]); st.modb++; }
             } else if (b == Freq[0] || b == Freq[1]) {
@@ -243,11 +242,11 @@ void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
     KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, bfq_grid(n, 256), 256, lcp, n, K, in);
 }
 
-void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, u8 *modsym)
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n)
 {
     if (!n) return;
     ClusterArgs a;
-    a.R = R; a.bwt = bwt; a.qual = qual; a.in = in; a.modsym = modsym; a.n = n;
+    a.R = R; a.bwt = bwt; a.qual = qual; a.in = in; a.n = n;
     a.m = c->P.m; a.v = c->P.v; a.f = c->P.f; a.t = c->P.t; a.term = c->P.term & 0xFF; a.M = c->P.M; a.ext = c->P.ext;
     a.powtab = c->d_powtab; a.qthr = c->d_qthr; a.qthrLo = c->qthrLo; a.qthrN = c->qthrN;
     a.cnt = c->d_cnt;

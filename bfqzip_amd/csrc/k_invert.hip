@@ -4,10 +4,9 @@
 // per read (the lock-step formulation of bfq_ext's BCRdecode, decode.cpp:499-686):
 // read i starts at row i; each step emits (replacement or eBWT symbol, quality
 // -- Illumina-binned when B=1, bfq_int.cpp:784-786) and moves to LF(row) until
-// the terminator row.  One step = ONE 64-byte rank block (counters, bit planes,
-// quality byte, replaced flag: bfq_rank.h); the replacement symbol is fetched from
-// modsym[] only for the ~1% flagged rows.  N walks in flight hide the dependent-
-// load latency; output bytes are collected in registers and stored 8 at a time.
+// the terminator row.  One step = ONE 8-byte read of the LF table (bfq_rank.h);
+// N walks in flight hide the dependent-load latency; output bytes are collected in
+// registers and stored 8 at a time.
 #include "bfq_internal.h"
 #include "bfq_device.h"
 #include "bfq_rank.h"
@@ -18,10 +17,9 @@ __global__ __launch_bounds__(256) void k_invert_count(RankIndex R, u64 N, u32 *_
         u64 j = i;
         u32 len = 0;
         for (;;) {
-            RankHdr h = rank_load_hdr(R, j);
-            u32 code = rank_hdr_code(h, j);
-            if (!code) break;
-            u64 nx = rank_hdr_lf(R, h, j, code);
+            u64 x = R.lfq[j];
+            if (!lfq_code(x)) break;
+            u64 nx = lfq_next(x);
             if (++len > BFQ_MAX_READ_LEN || nx >= R.n) { atomicAdd(&cnt->errInvert, 1ull); break; }
             j = nx;
         }
@@ -34,9 +32,8 @@ __device__ __forceinline__ void flush_bytes(u8 *dst, u64 from, u64 to, u64 acc) 
     for (u64 p = from; p < to; p++) dst[p] = (u8)(acc >> (8 * (p & 7)));
 }
 
-__global__ __launch_bounds__(256) void k_invert(RankIndex R, const u8 *__restrict__ modsym, u64 N,
-                                                const u64 *__restrict__ roff, int B, u8 *__restrict__ out_bases,
-                                                u8 *__restrict__ out_quals, DevCounters *cnt)
+__global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *__restrict__ roff, int B,
+                                                u8 *__restrict__ out_bases, u8 *__restrict__ out_quals, DevCounters *cnt)
 {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
         const u64 lo = roff[i], end = roff[i + 1];
@@ -44,14 +41,12 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, const u8 *__restric
         u64 accb = 0, accq = 0;
         bool bad = false;
         while (pos > lo) {
-            RankHdr h = rank_load_hdr(R, j);
-            u32 q = R.blk[j >> 5].q[j & 31];
-            u32 code = rank_hdr_code(h, j);
-            if (!code) { bad = true; break; }                        // walk ended before the read did
-            u64 nx = rank_hdr_lf(R, h, j, code);
-            if (nx >= R.n) { bad = true; break; }
-            u32 sym = bfq_code_sym(code);
-            if (q & 0x80u) { sym = modsym[j]; q &= 0x7Fu; }
+            u64 x = R.lfq[j];
+            u32 code = lfq_code(x);
+            u64 nx = lfq_next(x);
+            if (!code || nx >= R.n) { bad = true; break; }           // walk ended before the read did
+            u32 sym = bfq_code_sym(lfq_replaced(x) ? lfq_repl(x) : code);
+            u32 q = lfq_qual(x);
             if (B) q = bfq_bin8(q);
             --pos;
             u32 sh = (u32)(pos & 7) * 8;
@@ -75,7 +70,7 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, const u8 *__restric
             flush_bytes(out_bases, lo, hi, accb);
             flush_bytes(out_quals, lo, hi, accq);
         }
-        if (!bad && rank_code_at(R, j) != 0) bad = true;             // read longer than its slot
+        if (!bad && lfq_code(R.lfq[j]) != 0) bad = true;             // read longer than its slot
         if (bad) atomicAdd(&cnt->errInvert, 1ull);
     }
 }
@@ -86,10 +81,9 @@ void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens)
     KLAUNCH(c, K_INVERT_COUNT, 64.0 * (double)(R.n - N), k_invert_count, bfq_grid(N, 256), 256, R, N, lens, c->d_cnt);
 }
 
-void bfq_invert(bfq_ctx *c, const RankIndex &R, const u8 *modsym, u64 N, const u64 *d_roff, int B, u8 *out_bases,
-                u8 *out_quals)
+void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals)
 {
     if (!N) return;
-    KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert, bfq_grid(N, 256), 256, R, modsym, N, d_roff, B, out_bases,
-            out_quals, c->d_cnt);
+    KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert, bfq_grid(N, 256), 256, R, N, d_roff, B, out_bases, out_quals,
+            c->d_cnt);
 }
