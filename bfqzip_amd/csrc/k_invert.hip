@@ -7,6 +7,7 @@
 // the terminator row.  One step = ONE 8-byte read of the LF table (bfq_rank.h);
 // N walks in flight hide the dependent-load latency; output bytes are collected in
 // registers and stored 8 at a time.
+#include <stdlib.h>
 #include "bfq_internal.h"
 #include "bfq_device.h"
 #include "bfq_rank.h"
@@ -32,6 +33,7 @@ __device__ __forceinline__ void flush_bytes(u8 *dst, u64 from, u64 to, u64 acc) 
     for (u64 p = from; p < to; p++) dst[p] = (u8)(acc >> (8 * (p & 7)));
 }
 
+template <int NT>
 __global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *__restrict__ roff, int B,
                                                 u8 *__restrict__ out_bases, u8 *__restrict__ out_quals, DevCounters *cnt)
 {
@@ -41,7 +43,7 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *_
         u64 accb = 0, accq = 0;
         bool bad = false;
         while (pos > lo) {
-            u64 x = R.lfq[j];
+            u64 x = NT ? __builtin_nontemporal_load(R.lfq + j) : R.lfq[j];
             u32 code = lfq_code(x);
             u64 nx = lfq_next(x);
             if (!code || nx >= R.n) { bad = true; break; }           // walk ended before the read did
@@ -84,6 +86,11 @@ void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens)
 void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals)
 {
     if (!N) return;
-    KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert, bfq_grid(N, 256), 256, R, N, d_roff, B, out_bases, out_quals,
-            c->d_cnt);
+    static const int nt = getenv("BFQ_INVERT_NT") ? atoi(getenv("BFQ_INVERT_NT")) : 1;   // nt loads: -15% (L1 bypass)
+    if (nt)
+        KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert<1>, bfq_grid(N, 256), 256, R, N, d_roff, B, out_bases, out_quals,
+                c->d_cnt);
+    else
+        KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert<0>, bfq_grid(N, 256), 256, R, N, d_roff, B, out_bases, out_quals,
+                c->d_cnt);
 }
