@@ -6,6 +6,7 @@
 //   step 4  LF inversion -> reads
 // Everything runs on the context's stream inside one device workspace.
 #include <math.h>
+#include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
 #include <new>
@@ -114,6 +115,7 @@ extern "C" bfq_ctx *bfq_create(int device, const bfq_params *p)
         c = new bfq_ctx();
         c->device = device;
         if (p) c->P = *p; else bfq_default_params(&c->P);
+        if (getenv("BFQ_KEY_SYMS")) c->keySyms = atoi(getenv("BFQ_KEY_SYMS")) == 21 ? 21 : 16;
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_cnt, sizeof(DevCounters)));
@@ -264,9 +266,11 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     u8 *T8 = (u8 *)keysB, *Q8 = (u8 *)valsB;           // dead before the sort's first scatter
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
     bfq_build_keys(c, T8, Q8, text3, n, keysA, valsA);
-    bfq_radix_sort(c, keysA, valsA, keysB, valsB, n);
+    // radix-sorted prefix: 16 symbols (6 passes) while 16-mers stay selective, else all 21 (8 passes)
+    int ks = c->keySyms ? c->keySyms : (n <= (1ull << 33) ? 16 : 21);
+    bfq_radix_sort(c, keysA, valsA, keysB, valsB, n, ks);
     c->release(mB);                                     // segment lists reuse the B buffers
-    bfq_refine(c, keysA, valsA, text3, n, c->d_lcp, st);
+    bfq_refine(c, keysA, valsA, text3, n, ks, c->d_lcp, st);
     bfq_emit_bwt(c, valsA, n, termOut, c->d_bwt, c->d_qual);
     c->release(m0);
 }

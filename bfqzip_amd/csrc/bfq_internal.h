@@ -75,6 +75,7 @@ struct bfq_ctx {
     u64 n = 0, N = 0;
 
     // profiling
+    int keySyms = 0;                // 0 = choose per call: radix-sorted prefix length (16 or 21 symbols)
     bool profOn = true;
     std::vector<hipEvent_t> evPool;
     size_t evUsed = 0;
@@ -120,9 +121,9 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
                     u8 *T8, u8 *Q8, u64 *text3, u64 nwords);
 void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u64 *keys, u64 *vals);
 // LSD radix sort of (key,val) pairs on key bits [0,63); result ends in keysA/valsA
-void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, u64 n);
+void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, u64 n, int keySyms);
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
-void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
+void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n, int keySyms, u16 *lcp, bfq_stats *st);
 void bfq_emit_bwt(bfq_ctx *c, const u64 *vals, u64 n, int termOut, u8 *bwt, u8 *qs);
 // whole step 1 on device-resident reads; leaves c->d_bwt/d_qual/d_lcp
 void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,

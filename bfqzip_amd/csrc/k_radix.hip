@@ -135,7 +135,9 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(const u64 *__re
     }
 }
 
-void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, u64 n)
+// keySyms = 21: all 63 key bits (8 passes); keySyms = 16: only the first 16 symbols = bits 15..62
+// (6 passes) -- rows equal on them stay in position order and are finished by the refinement.
+void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, u64 n, int keySyms)
 {
     if (n < 2) return;
     u64 nb = ceil_div(n, RS_BLOCK_ELEMS);
@@ -143,8 +145,10 @@ void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, 
     u32 *hist = c->alloc<u32>(256 * nb);
     u64 *off = c->alloc<u64>(256 * nb);
     u64 *kin = keysA, *vin = valsA, *kout = keysB, *vout = valsB;
-    for (int pass = 0; pass < 8; pass++) {
-        int shift = pass * 8;
+    const int lowbit = 3 * (BFQ_SYMS_PER_WORD - keySyms);       // 0 or 15
+    const int npass = (63 - lowbit + 7) / 8;                     // 8 or 6: even, so the result returns to A
+    for (int pass = 0; pass < npass; pass++) {
+        int shift = lowbit + pass * 8;
         KLAUNCH(c, K_RADIX_HIST, 8.0 * (double)n, k_radix_hist, nb, RS_THREADS, (const u64 *)kin, n, shift, hist, nb);
         bfq_exscan_u32(c, hist, off, 256 * nb, nullptr);
         KLAUNCH(c, K_RADIX_SCATTER, 32.0 * (double)n, k_radix_scatter, nb, RS_THREADS, (const u64 *)kin,
@@ -152,6 +156,6 @@ void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, 
         u64 *t = kin; kin = kout; kout = t;
         t = vin; vin = vout; vout = t;
     }
-    // 8 passes: result is back in keysA / valsA
+    // an even number of passes: result is back in keysA / valsA
     c->release(m);
 }

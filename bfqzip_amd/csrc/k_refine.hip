@@ -19,14 +19,15 @@
 #define LCP_PENDING 0xFFFFu
 
 // head[r] = 1 if row r starts a segment; LCP of head rows comes from the keys
-__global__ __launch_bounds__(256) void k_seg_flags(const u64 *__restrict__ keys, u64 n, u8 *__restrict__ head,
+__global__ __launch_bounds__(256) void k_seg_flags(const u64 *__restrict__ keys, u64 n, int lowbit, u8 *__restrict__ head,
                                                    u16 *__restrict__ lcp)
 {
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
         u64 k = keys[r];
         if (r == 0) { head[0] = 1; lcp[0] = 0; continue; }
         u64 kp = keys[r - 1];
-        bool h = (k != kp) || bfq_key_has_term(k);
+        // only the radix-sorted prefix (bits >= lowbit) delimits segments; a terminator inside it = complete suffix
+        bool h = (((k ^ kp) >> lowbit) != 0) || ((bfq_zero_fields(k) >> lowbit) != 0);
         head[r] = h ? 1 : 0;
         lcp[r] = h ? (u16)bfq_key_lcp(kp, k) : (u16)LCP_PENDING;
     }
@@ -110,7 +111,7 @@ __device__ __forceinline__ u32 bfq_wave_max32(u32 v)
 //   one ds_permute of the payload, new sub-segment heads and their LCP from the words.
 __global__ __launch_bounds__(256) void k_refine_wave(const u64 *__restrict__ seglist, u64 nseg, u64 *__restrict__ vals,
                                                      u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
-                                                     u64 *__restrict__ biglist, DevCounters *cnt)
+                                                     u32 depth0, u64 *__restrict__ biglist, DevCounters *cnt)
 {
     const u32 lane = bfq_lane();
     const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(256) void k_refine_wave(const u64 *__restrict__ seg
             u64 v = act ? vals[myRow] : 0ull;
             u32 mylcp = LCP_PENDING;                                            // positional: LCP(row-1,row)
             u64 unres = __ballot(act);
-            u32 depth = BFQ_SYMS_PER_WORD;
+            u32 depth = depth0;
             u64 Wn = act ? bfq_key_at(text3, bfq_val_pos(v) + depth) : 0ull;
             while (unres) {
                 const bool un = (unres >> lane) & 1ull;
@@ -185,29 +186,29 @@ __global__ __launch_bounds__(256) void k_refine_wave(const u64 *__restrict__ seg
 
 // ---- larger segments: one workgroup each, bitonic network in global memory -------
 // full-suffix order beyond the first 21 symbols; ties (identical suffixes) by position
-__device__ bool suffix_less(const u64 *__restrict__ text3, u64 pa, u64 pb)
+__device__ bool suffix_less(const u64 *__restrict__ text3, u64 pa, u64 pb, u32 depth0)
 {
-    for (u32 d = BFQ_SYMS_PER_WORD;; d += BFQ_SYMS_PER_WORD) {
+    for (u32 d = depth0;; d += BFQ_SYMS_PER_WORD) {
         u64 a = bfq_key_at(text3, pa + d), b = bfq_key_at(text3, pb + d);
         if (a != b) return a < b;
         if (bfq_key_has_term(a)) return pa < pb;
     }
 }
-__device__ u32 suffix_lcp(const u64 *__restrict__ text3, u64 pa, u64 pb)
+__device__ u32 suffix_lcp(const u64 *__restrict__ text3, u64 pa, u64 pb, u32 depth0)
 {
-    for (u32 d = BFQ_SYMS_PER_WORD;; d += BFQ_SYMS_PER_WORD) {
+    for (u32 d = depth0;; d += BFQ_SYMS_PER_WORD) {
         u64 a = bfq_key_at(text3, pa + d), b = bfq_key_at(text3, pb + d);
         if (a != b || bfq_key_has_term(a)) return d + (u32)bfq_key_lcp(a, b);
     }
 }
 
-__device__ __forceinline__ void big_step(u64 *a, u64 g, u64 j, const u64 *__restrict__ text3)
+__device__ __forceinline__ void big_step(u64 *a, u64 g, u64 j, const u64 *__restrict__ text3, u32 depth0)
 {
     for (u64 i = threadIdx.x; i < g; i += 256) {
         u64 l = i ^ j;
         if (l > i && l < g) {                      // rows >= g are a virtual +inf padding
             u64 va = a[i], vb = a[l];
-            if (suffix_less(text3, bfq_val_pos(vb), bfq_val_pos(va))) { a[i] = vb; a[l] = va; }
+            if (suffix_less(text3, bfq_val_pos(vb), bfq_val_pos(va), depth0)) { a[i] = vb; a[l] = va; }
         }
     }
     __syncthreads();
@@ -215,7 +216,7 @@ __device__ __forceinline__ void big_step(u64 *a, u64 g, u64 j, const u64 *__rest
 
 __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ biglist, u64 nbig, u64 *__restrict__ vals,
                                                     const u8 *__restrict__ head, u16 *__restrict__ lcp,
-                                                    const u64 *__restrict__ text3, u64 n)
+                                                    const u64 *__restrict__ text3, u64 n, u32 depth0)
 {
     __shared__ u64 shEnd;
     for (u64 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
@@ -239,11 +240,11 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
     // bitonic network with ascending comparators only: flip (i <-> i^(k-1)) then
     // disperse (i <-> i^j, j = k/4 .. 1); the +inf padding beyond g never moves
     for (u64 k = 2; k <= P; k <<= 1) {
-        big_step(a, g, k - 1, text3);
-        for (u64 j = k >> 2; j >= 1; j >>= 1) big_step(a, g, j, text3);
+        big_step(a, g, k - 1, text3, depth0);
+        for (u64 j = k >> 2; j >= 1; j >>= 1) big_step(a, g, j, text3, depth0);
     }
     for (u64 i = 1 + threadIdx.x; i < g; i += 256)
-        lcp[s + i] = (u16)suffix_lcp(text3, bfq_val_pos(a[i - 1]), bfq_val_pos(a[i]));
+        lcp[s + i] = (u16)suffix_lcp(text3, bfq_val_pos(a[i - 1]), bfq_val_pos(a[i]), depth0);
     }
 }
 
@@ -259,12 +260,13 @@ __global__ __launch_bounds__(256) void k_emit_bwt(const u64 *__restrict__ vals, 
     }
 }
 
-void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st)
+void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n, int keySyms, u16 *lcp, bfq_stats *st)
 {
+    const int lowbit = 3 * (BFQ_SYMS_PER_WORD - keySyms);
     if (!n) return;
     size_t m = c->mark();
     u8 *head = c->alloc<u8>(n + 64);
-    KLAUNCH(c, K_SEG_FLAGS, 19.0 * (double)n, k_seg_flags, bfq_grid(n, 256), 256, keys, n, head, lcp);
+    KLAUNCH(c, K_SEG_FLAGS, 19.0 * (double)n, k_seg_flags, bfq_grid(n, 256), 256, keys, n, lowbit, head, lcp);
     u64 nchunks = ceil_div(n, SG_CHUNK);
     u32 *counts = c->alloc<u32>(nchunks);
     u64 *bases = c->alloc<u64>(nchunks);
@@ -281,14 +283,14 @@ void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n,
         KLAUNCH(c, K_SEG_COMPACT, (double)n + 8.0 * (double)nseg, k_seg_write, nchunks, 256, (const u8 *)head, n,
                 (const u64 *)bases, seglist);
         KLAUNCH(c, K_REFINE_WAVE, 26.0 * (double)n, k_refine_wave, bfq_grid(ceil_div(nseg, 64), 4), 256,
-                (const u64 *)seglist, nseg, vals, lcp, text3, n, biglist, c->d_cnt);
+                (const u64 *)seglist, nseg, vals, lcp, text3, n, (u32)keySyms, biglist, c->d_cnt);
         u64 nbig = 0;
         HIP_CHECK(hipMemcpyAsync(&nbig, &c->d_cnt->bigCount, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
         c->sync();
         if (st) st->n_big_segments = nbig;
         if (nbig)
             KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, bfq_grid(nbig, 1), 256, (const u64 *)biglist, nbig, vals, (const u8 *)head,
-                    lcp, text3, n);
+                    lcp, text3, n, (u32)keySyms);
     }
     c->release(m);
 }
