@@ -28,6 +28,20 @@ __device__ __forceinline__ u64 bfq_permute64(u64 v, int dstLane)     // push to 
     return ((u64)hi << 32) | lo;
 }
 
+// whole-wavefront shifts by one lane (DPP wave_shl / wave_shr, gfx9): VALU moves, no LDS round trip
+__device__ __forceinline__ u64 bfq_from_next_lane(u64 v)   // lane i <- lane i+1 (lane 63 <- 0)
+{
+    u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x130, 0xF, 0xF, true);
+    u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x130, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 bfq_from_prev_lane(u64 v)   // lane i <- lane i-1 (lane 0 <- 0)
+{
+    u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)v, 0x138, 0xF, 0xF, true);
+    u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(v >> 32), 0x138, 0xF, 0xF, true);
+    return ((u64)hi << 32) | lo;
+}
+
 // inclusive wave scan (sum) of u64 / u32
 __device__ __forceinline__ u64 bfq_wave_incscan64(u64 v)
 {

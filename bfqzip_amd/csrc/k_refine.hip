@@ -155,9 +155,11 @@ __global__ __launch_bounds__(256) void k_refine_wave(const u64 *__restrict__ seg
                 Wn = (un && !bfq_key_has_term(W)) ? bfq_key_at(text3, bfq_val_pos(v) + depth + BFQ_SYMS_PER_WORD) : 0ull;
                 u32 maxsz = bfq_wave_max32(un ? (u32)(subhi - sublo) : 0u);
                 int c = 0;
+                u64 Wu = W, Wd = W;                                             // W of lane+d / lane-d, shifted one lane per step
                 for (u32 d = 1; d < maxsz; d++) {
                     int up = (int)lane + (int)d, dn = (int)lane - (int)d;
-                    u64 Wu = bfq_bpermute64(W, up), Wd = bfq_bpermute64(W, dn);
+                    Wu = bfq_from_next_lane(Wu);
+                    Wd = bfq_from_prev_lane(Wd);
                     if (un && up < subhi && Wu < W) c++;
                     if (un && dn >= sublo && Wd <= W) c++;
                 }
