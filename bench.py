@@ -93,12 +93,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    backend = os.environ.get("BFQ_BENCH_BACKEND", "nccl")     # "gloo": rehearsal of the N>1 path on fewer GPUs than ranks
+    local = local % max(1, torch.cuda.device_count())
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    cdev = dev if backend == "nccl" else torch.device("cpu")   # where the few exchanged integers live
 
     tstart = time.perf_counter()
     N, L = parse_workload(args.workload)
@@ -137,13 +142,13 @@ def main():
     for _ in range(args.steps):
         st = step()
         if world > 1:                                   # the only exchange: per-block output sizes (8 integers)
-            sz = torch.tensor([total], dtype=torch.int64, device=dev)
+            sz = torch.tensor([total], dtype=torch.int64, device=cdev)
             lst = [torch.empty_like(sz) for _ in range(world)]
             dist.all_gather(lst, sz)
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     prof = eng.prof()

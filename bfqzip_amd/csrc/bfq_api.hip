@@ -230,6 +230,7 @@ static void fill_stats(bfq_ctx *c, bfq_stats *st)
     st->num_clust_mod = s[3]; st->num_clust_alleq = s[4]; st->bases_inside = s[5];
     st->qs_smoothed = s[6]; st->modified = s[7];
     st->n_rows = c->n; st->n_reads = c->N;
+    st->n_segments = c->h_cnt.nSegs; st->n_big_segments = c->h_cnt.bigCount;
 }
 
 // workspace bound for a collection of n rows (see DESIGN.md "HBM layout")

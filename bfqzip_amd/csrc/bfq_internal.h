@@ -40,7 +40,8 @@ struct DevCounters {
     u64 errTooLong;      // >0: read longer than BFQ_MAX_READ_LEN
     u64 tot[6];          // symbol totals of the eBWT: # A C G N T
     u64 mismatch;        // >0: rebuilt eBWT differs from the given one
-    u64 pad[11];
+    u64 nSegs;           // segments of >= 2 rows met by the refinement
+    u64 pad[10];
 };
 
 // the tabulated rank queries: one u64 per eBWT row (layout: bfq_rank.h)

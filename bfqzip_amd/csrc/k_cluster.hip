@@ -186,53 +186,39 @@ __device__ __forceinline__ void process_cluster(const ClusterArgs &a, u64 start,
     if (st.modb) atomicAdd(&shst[7], st.modb);
 }
 
-// ---- compaction of the cluster starts (rows r with in(r) && !in(r-1)) -----------------
+// ---- one workgroup per chunk of rows: the chunk's cluster starts (rows r with in(r) && !in(r-1))
+// are compacted into LDS, then every thread takes clusters from that list (dense lanes) and
+// walks them in row order exactly as the reference does.  A cluster belongs to the chunk it
+// starts in; its rows may extend past the chunk end.
 #define CL_CHUNK 4096
-__device__ __forceinline__ bool cl_start(const u8 *in, u64 r, u64 n) { return r >= 1 && r < n && in[r] && !in[r - 1]; }
-
-__global__ __launch_bounds__(256) void k_cl_count(const u8 *__restrict__ in, u64 n, u32 *__restrict__ counts, u64 nchunks)
-{
-    __shared__ u32 sh[4];
-    for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        u64 base = ch * CL_CHUNK;
-        u32 c = 0;
-        for (int k = 0; k < CL_CHUNK / 256; k++) c += cl_start(in, base + (u64)k * 256 + threadIdx.x, n) ? 1u : 0u;
-        u32 tot;
-        bfq_block_exscan32(c, sh, &tot);
-        if (threadIdx.x == 0) counts[ch] = tot;
-    }
-}
-__global__ __launch_bounds__(256) void k_cl_write(const u8 *__restrict__ in, u64 n, const u64 *__restrict__ chunkBase,
-                                                  u64 *__restrict__ starts, u64 nchunks)
-{
-    __shared__ u32 sh[4];
-    for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        u64 base = ch * CL_CHUNK;
-        u64 out = chunkBase[ch];
-        for (int k = 0; k < CL_CHUNK / 256; k++) {
-            u64 r = base + (u64)k * 256 + threadIdx.x;
-            bool s = cl_start(in, r, n);
-            u32 tot;
-            u32 ex = bfq_block_exscan32(s ? 1u : 0u, sh, &tot);
-            if (s) starts[out + ex] = r;
-            out += tot;
-        }
-    }
-}
-
-// one thread per cluster (dense): walks it in row order exactly as the reference does
-__global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, const u64 *__restrict__ starts, u64 nclust)
+__global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
 {
     __shared__ u32 shst[8];
+    __shared__ u32 sh[4];
+    __shared__ u16 starts[CL_CHUNK];
     if (threadIdx.x < 8) shst[threadIdx.x] = 0;
     __syncthreads();
-    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < nclust; t += (u64)gridDim.x * blockDim.x) {
-        u64 r = starts[t];
-        u64 e = r;
-        while (e + 1 < a.n && a.in[e + 1]) e++;
-        process_cluster(a, r - 1, e, shst);
+    for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        u64 base = ch * CL_CHUNK;
+        u32 out = 0;
+        for (int k = 0; k < CL_CHUNK / 256; k++) {                 // chunk order = row order
+            u32 li = k * 256 + threadIdx.x;
+            u64 r = base + li;
+            bool s = r >= 1 && r < a.n && a.in[r] && !a.in[r - 1];
+            u32 tot;
+            u32 ex = bfq_block_exscan32(s ? 1u : 0u, sh, &tot);
+            if (s) starts[out + ex] = (u16)li;
+            out += tot;
+        }
+        __syncthreads();
+        for (u32 t = threadIdx.x; t < out; t += 256) {
+            u64 r = base + starts[t];
+            u64 e = r;
+            while (e + 1 < a.n && a.in[e + 1]) e++;
+            process_cluster(a, r - 1, e, shst);
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (threadIdx.x < 8 && shst[threadIdx.x]) atomicAdd(&a.cnt->stats[threadIdx.x], (u64)shst[threadIdx.x]);
 }
 
@@ -250,21 +236,6 @@ void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual,
     a.m = c->P.m; a.v = c->P.v; a.f = c->P.f; a.t = c->P.t; a.term = c->P.term & 0xFF; a.M = c->P.M; a.ext = c->P.ext;
     a.powtab = c->d_powtab; a.qthr = c->d_qthr; a.qthrLo = c->qthrLo; a.qthrN = c->qthrN;
     a.cnt = c->d_cnt;
-    size_t m = c->mark();
     u64 nchunks = ceil_div(n, CL_CHUNK);
-    u32 *counts = c->alloc<u32>(nchunks);
-    u64 *bases = c->alloc<u64>(nchunks);
-    u64 *d_total = c->alloc<u64>(1);
-    KLAUNCH(c, K_CLUSTER_COMPACT, (double)n, k_cl_count, bfq_grid(nchunks, 1), 256, in, n, counts, nchunks);
-    bfq_exscan_u32(c, counts, bases, nchunks, d_total);
-    u64 nclust = 0;
-    HIP_CHECK(hipMemcpyAsync(&nclust, d_total, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
-    c->sync();
-    if (nclust) {
-        u64 *starts = c->alloc<u64>(nclust);
-        KLAUNCH(c, K_CLUSTER_COMPACT, (double)n + 8.0 * (double)nclust, k_cl_write, bfq_grid(nchunks, 1), 256, in, n,
-                (const u64 *)bases, starts, nchunks);
-        KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, bfq_grid(nclust, 256), 256, a, (const u64 *)starts, nclust);
-    }
-    c->release(m);
+    KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, bfq_grid(nchunks, 1), 256, a, nchunks);
 }
