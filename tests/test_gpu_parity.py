@@ -141,3 +141,58 @@ def test_device_resident_and_synth_device(engine, orc):
         assert est[k] == st[k]
     prof = engine.prof()
     assert "k_radix_scatter" in prof and prof["k_radix_scatter"]["launches"] >= 8
+
+
+def test_bfq_ext_arithmetic(engine, orc):
+    """bfq_ext's M=3 rounding (round((float)sum/num), bfq_ext.cpp:496) and uchar M=1 result, as the
+    oracle restates them (the reference bfq_ext cannot be built here without stand-ins: unpinned)."""
+    sp = api.synth_spec(3000, 50, seed=321, coverage=25)
+    b, q, r = api.synth_host(sp)
+    bwt, qs, lcp = orc.build_ebwt(b, q, r)
+    for M in (1, 3):
+        engine.set_params(m=5, M=M, ext=1)
+        p = orc.params(m=5, M=M, ext=1)
+        ob, oq, oroff, st = orc.smooth_invert(bwt, qs, lcp, p)
+        gb, gq, groff, gst = engine.smooth_invert(bwt, qs, np.minimum(lcp, 255).astype(np.uint8))   # 1-byte LCP file (--lbytes 1)
+        assert np.array_equal(gb, ob) and np.array_equal(gq, oq) and np.array_equal(groff, oroff)
+        assert gst["qs_smoothed"] == st["qs_smoothed"]
+    # the two roundings really differ somewhere
+    engine.set_params(m=5, M=3, ext=0)
+    ib, iq, _, _ = engine.smooth_invert(bwt, qs, lcp.astype(np.uint16))
+    assert not np.array_equal(iq, gq)
+
+
+def test_full_size_properties(engine):
+    """BASELINE.json configs[2] size (30 M x 150 bp, n = 4.53 G rows) through size-independent properties:
+    K above every LCP -> no cluster -> the output must be the input (sort + LF round trip);
+    default run -> edits are consistent with the statistics and with the M=2 rule."""
+    torch = pytest.importorskip("torch")
+    free, total = torch.cuda.mem_get_info()
+    N, L = (30_000_000, 150) if free > 200 * 2**30 else (2_000_000, 150)
+    sp = api.synth_spec(N, L, seed=4242)
+    tot = N * L
+    dev = torch.device("cuda:0")
+    db = torch.empty(tot, dtype=torch.uint8, device=dev); dq = torch.empty_like(db)
+    dr = torch.empty(N + 1, dtype=torch.int64, device=dev)
+    ob = torch.empty_like(db); oq = torch.empty_like(db)
+    engine.synth_device(sp, db.data_ptr(), dq.data_ptr(), dr.data_ptr())
+    torch.cuda.synchronize()
+    assert int(dr[-1].item()) == tot and bool((dr[1:] - dr[:-1] == L).all())
+    run = lambda: engine.run_reads_device(db.data_ptr(), dq.data_ptr(), dr.data_ptr(), N, tot, ob.data_ptr(), oq.data_ptr())
+    engine.set_params(k=10000, m=5)
+    st = run(); torch.cuda.synchronize()
+    assert st["num_clust"] == 0 and st["n_rows"] == tot + N and st["n_reads"] == N
+    assert torch.equal(ob, db) and torch.equal(oq, dq)                      # identity round trip
+    engine.set_params(k=16, m=5, M=2, B=0, v=ord(">"))
+    st = run(); torch.cuda.synchronize()
+    changed_b = ob != db
+    changed_q = oq != dq
+    assert int(changed_b.sum().item()) == st["modified"]                   # every replacement changes the base
+    assert 0 < int(changed_q.sum().item()) <= st["qs_smoothed"]
+    assert bool(((oq == ord(">")) | ~changed_q).all())                     # M=2: smoothed qualities are the constant
+    assert not bool((changed_b & changed_q).any())                         # a replaced base keeps its quality
+    assert bool(((ob == ord("N")) <= (db == ord("N"))).all())              # N is never written
+    st2 = run(); torch.cuda.synchronize()
+    assert st2 == st                                                        # deterministic
+    del db, dq, ob, oq
+    torch.cuda.empty_cache()
