@@ -23,6 +23,25 @@ def alg_bytes_per_base(L):
     return (L + 1) / L * (352.7 + 3 * (L + 1) / 16)
 
 
+def pmc_traffic(kernel, rows):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/traffic_per_row.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same bench command; FETCH doubled for the
+    coalesced streaming kernels as MI355X_MICROARCH.md prescribes, raw for random sector reads).  None if absent."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_per_row.json"))):
+        try:
+            best = json.load(open(p))
+        except Exception:
+            pass
+    if not best or kernel not in best.get("kernels", {}):
+        return None
+    k = best["kernels"][kernel]
+    streaming = kernel not in ("k_invert", "k_invert<1>", "k_invert<0>", "k_refine_chunk", "k_cluster")
+    fetch = k["fetch_B_per_row_raw"] * (2.0 if streaming else 1.0)
+    return round((fetch + k["write_B_per_row"]) * rows)
+
+
 def parse_workload(w):
     a, b = w.lower().split("x")
     mult = 1
@@ -163,7 +182,7 @@ def main():
         avg_ms = d["ms"] / d["launches"]
         ach = d["alg_bytes"] / d["launches"] / (avg_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": dname, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dname, N * (L + 1)),
                 "avg_launch_ms": round(avg_ms, 4), "launches": int(d["launches"]),
                 "alg_bytes_per_launch": d["alg_bytes"] / d["launches"],
                 "job_alg_bytes_per_base": round(alg_bytes_per_base(L), 1),
