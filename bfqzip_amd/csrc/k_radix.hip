@@ -14,7 +14,7 @@
 
 #define RS_THREADS 256
 #define RS_WAVES 4
-#define RS_ROUNDS 16                                // items per thread
+#define RS_ROUNDS 12                                // items per thread
 #define RS_TILE (RS_THREADS * RS_ROUNDS)            // 4096 pairs per tile
 #define RS_TILES_PER_BLOCK 8
 #define RS_BLOCK_ELEMS ((u64)RS_TILE * RS_TILES_PER_BLOCK)
