@@ -20,6 +20,8 @@ def _run(cmd, **kw):
 def tools():
     t = {k: os.path.join(DROP, p) for k, p in dict(gsufsort="external/gsufsort/gsufsort", egap="external/egap/eGap",
                                                    bfq_int="src_int_mem/bfq_int", bfq_ext="src_ext_mem/bfq_ext").items()}
+    if not all(os.path.exists(p) for p in t.values()):          # normally prebuilt by __graft_entry__.build()
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bfqzip_amd", "csrc"), "cli"])
     for p in t.values():
         assert os.path.exists(p), f"{p} missing: run __graft_entry__.build()"
     return t
