@@ -171,11 +171,48 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
     }
 }
 
-// statistics of one cluster go straight to the workgroup's LDS counters (bfq_int.cpp:53-62)
-__device__ __forceinline__ void process_cluster(const ClusterArgs &a, u64 start, u64 end, u32 *shst)
+// ---- one workgroup per chunk of rows: the chunk's cluster starts (rows r with in(r) && !in(r-1))
+// are compacted into LDS (per-wave ballots, one prefix over the four waves), then every thread
+// takes clusters from that list (dense lanes) and walks them in row order exactly as the
+// reference does.  A cluster belongs to the chunk it starts in; its rows may extend past the
+// chunk end.  Statistics (bfq_int.cpp:53-62) stay in per-thread scalars until the kernel ends.
+#define CL_CHUNK 4096
+#define CL_WROWS (CL_CHUNK / 4)                       // rows per wave
+__global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
 {
+    __shared__ u32 shst[8];
+    __shared__ u16 starts[4][CL_WROWS];               // per wave: chunk-local start rows
+    __shared__ u32 wn[4];
+    const u32 lane = bfq_lane(), w = threadIdx.x >> 6;
+    const u64 ltmask = bfq_lanemask_lt();
+    if (threadIdx.x < 8) shst[threadIdx.x] = 0;
     ClStat st = {0, 0, 0, 0, 0, 0, 0, 0};
-    process_cluster_body(a, start, end, st);
+    for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        u64 base = ch * CL_CHUNK + (u64)w * CL_WROWS;
+        u32 cntw = 0;
+#pragma unroll 2
+        for (int k = 0; k < CL_WROWS / 64; k++) {                  // wave order = row order
+            u32 li = k * 64 + lane;
+            u64 r = base + li;
+            bool s = r >= 1 && r < a.n && a.in[r] && !a.in[r - 1];
+            u64 m = __ballot(s);
+            if (s) starts[w][cntw + (u32)__popcll(m & ltmask)] = (u16)(w * CL_WROWS + li);
+            cntw += (u32)__popcll(m);
+        }
+        if (lane == 0) wn[w] = cntw;
+        __syncthreads();
+        u32 n0 = wn[0], n1 = wn[1], n2 = wn[2], n3 = wn[3];
+        u32 total = n0 + n1 + n2 + n3;
+        for (u32 t = threadIdx.x; t < total; t += 256) {
+            u32 ww = t < n0 ? 0u : (t < n0 + n1 ? 1u : (t < n0 + n1 + n2 ? 2u : 3u));
+            u32 idx = t - (ww == 0 ? 0u : (ww == 1 ? n0 : (ww == 2 ? n0 + n1 : n0 + n1 + n2)));
+            u64 r = ch * CL_CHUNK + starts[ww][idx];
+            u64 e = r;
+            while (e + 1 < a.n && a.in[e + 1]) e++;
+            process_cluster_body(a, r - 1, e, st);
+        }
+        __syncthreads();
+    }
     if (st.clust) atomicAdd(&shst[0], st.clust);
     if (st.disc) atomicAdd(&shst[1], st.disc);
     if (st.amb) atomicAdd(&shst[2], st.amb);
@@ -184,41 +221,7 @@ __device__ __forceinline__ void process_cluster(const ClusterArgs &a, u64 start,
     if (st.bases) atomicAdd(&shst[5], st.bases);
     if (st.qs) atomicAdd(&shst[6], st.qs);
     if (st.modb) atomicAdd(&shst[7], st.modb);
-}
-
-// ---- one workgroup per chunk of rows: the chunk's cluster starts (rows r with in(r) && !in(r-1))
-// are compacted into LDS, then every thread takes clusters from that list (dense lanes) and
-// walks them in row order exactly as the reference does.  A cluster belongs to the chunk it
-// starts in; its rows may extend past the chunk end.
-#define CL_CHUNK 4096
-__global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
-{
-    __shared__ u32 shst[8];
-    __shared__ u32 sh[4];
-    __shared__ u16 starts[CL_CHUNK];
-    if (threadIdx.x < 8) shst[threadIdx.x] = 0;
     __syncthreads();
-    for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        u64 base = ch * CL_CHUNK;
-        u32 out = 0;
-        for (int k = 0; k < CL_CHUNK / 256; k++) {                 // chunk order = row order
-            u32 li = k * 256 + threadIdx.x;
-            u64 r = base + li;
-            bool s = r >= 1 && r < a.n && a.in[r] && !a.in[r - 1];
-            u32 tot;
-            u32 ex = bfq_block_exscan32(s ? 1u : 0u, sh, &tot);
-            if (s) starts[out + ex] = (u16)li;
-            out += tot;
-        }
-        __syncthreads();
-        for (u32 t = threadIdx.x; t < out; t += 256) {
-            u64 r = base + starts[t];
-            u64 e = r;
-            while (e + 1 < a.n && a.in[e + 1]) e++;
-            process_cluster(a, r - 1, e, shst);
-        }
-        __syncthreads();
-    }
     if (threadIdx.x < 8 && shst[threadIdx.x]) atomicAdd(&a.cnt->stats[threadIdx.x], (u64)shst[threadIdx.x]);
 }
 
