@@ -20,11 +20,6 @@ __device__ __forceinline__ u32 row_code(const u8 *__restrict__ bwt, u64 r, u64 n
     if (code == BFQ_CODE_INVALID) { if (cnt) atomicAdd(&cnt->errSymbol, 1ull); code = 4; }
     return code;
 }
-__device__ __forceinline__ u64 code_peers(u32 code)   // lanes of the wave holding the same code
-{
-    u64 b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u);
-    return ((code & 1u) ? b0 : ~b0) & ((code & 2u) ? b1 : ~b1) & ((code & 4u) ? b2 : ~b2);
-}
 
 __global__ __launch_bounds__(256) void k_lf_count(const u8 *__restrict__ bwt, u64 n, u32 term, u32 *__restrict__ gcnt,
                                                   u64 ngroups, DevCounters *cnt)
@@ -33,13 +28,11 @@ __global__ __launch_bounds__(256) void k_lf_count(const u8 *__restrict__ bwt, u6
     const u32 lane = bfq_lane(), w = threadIdx.x >> 6;
     for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
         u32 code = row_code(bwt, g * 256 + threadIdx.x, n, term, cnt);
-        u64 peers = code_peers(code);
         u64 b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u);
         if (lane < 6) {
             u64 m = ((lane & 1u) ? b0 : ~b0) & ((lane & 2u) ? b1 : ~b1) & ((lane & 4u) ? b2 : ~b2);
             wc[w][lane] = (u32)__popcll(m);
         }
-        (void)peers;
         __syncthreads();
         if (threadIdx.x < 6) gcnt[(u64)threadIdx.x * ngroups + g] = wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x];
         __syncthreads();

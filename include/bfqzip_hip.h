@@ -101,8 +101,9 @@ int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_qu
                          uint8_t *d_out_bases, uint8_t *d_out_quals, bfq_stats *st);
 
 /* Device-resident eBWT of the last bfq_run_reads*() / bfq_build_ebwt() call
- * (valid until the next call on the context): copies to host. Any may be NULL. */
-int bfq_fetch_ebwt(bfq_ctx *c, uint8_t *h_bwt, uint8_t *h_bwtqs_smoothed, uint16_t *h_lcp16);
+ * (valid until the next call on the context): copies to host. Any may be NULL.
+ * h_bwtqs receives the permuted qualities as built (before smoothing). */
+int bfq_fetch_ebwt(bfq_ctx *c, uint8_t *h_bwt, uint8_t *h_bwtqs, uint16_t *h_lcp16);
 
 /* ---- synthetic reads (seeded, counter based; DESIGN.md "synthetic workload").
  * Fixed length L when Lmin == Lmax.  Host and device versions produce identical
