@@ -115,7 +115,6 @@ extern "C" bfq_ctx *bfq_create(int device, const bfq_params *p)
         c = new bfq_ctx();
         c->device = device;
         if (p) c->P = *p; else bfq_default_params(&c->P);
-        if (getenv("BFQ_KEY_SYMS")) c->keySyms = atoi(getenv("BFQ_KEY_SYMS")) == 21 ? 21 : 16;
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_cnt, sizeof(DevCounters)));
@@ -240,7 +239,7 @@ static size_t ws_need(u64 n, u64 N, u64 extra)
     size_t need = 0;
     need += 4 * (n + 256) + 1024;                       // bwt, qual, lcp16
     need += 8 * (n / 21 + 8);                           // packed text
-    need += 4 * 8 * (n + 256);                          // key/payload ping-pong
+    need += 6 * 4 * (n + 256);                          // sort records, ping-pong (2 x 12 B/row)
     need += 256 * nb * 12 + (nb + 4096) * 64;           // radix histograms + scan partials
     need += 16 * (N + 64);                              // offsets / lengths
     need += extra + (64u << 20);
@@ -252,7 +251,7 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
                       int termOut, bfq_stats *st)
 {
     u64 n = total + N;
-    if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^40 rows)"};
+    if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^37 rows)"};
     c->n = n; c->N = N;
     c->d_bwt = c->alloc<u8>(n + 64);
     c->d_qual = c->alloc<u8>(n + 64);
@@ -261,18 +260,17 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     size_t m0 = c->mark();
     u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
     u64 *text3 = c->alloc<u64>(nwords);
-    u64 *keysA = c->alloc<u64>(n + 8), *valsA = c->alloc<u64>(n + 8);
+    SortRec A, B;
+    A.w0 = c->alloc<u32>(n + 16); A.w1 = c->alloc<u32>(n + 16); A.w2 = c->alloc<u32>(n + 16);
     size_t mB = c->mark();
-    u64 *keysB = c->alloc<u64>(n + 8), *valsB = c->alloc<u64>(n + 8);
-    u8 *T8 = (u8 *)keysB, *Q8 = (u8 *)valsB;           // dead before the sort's first scatter
+    B.w0 = c->alloc<u32>(n + 16); B.w1 = c->alloc<u32>(n + 16); B.w2 = c->alloc<u32>(n + 16);
+    u8 *T8 = (u8 *)B.w0, *Q8 = (u8 *)B.w1;             // dead before the sort's first scatter
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
-    bfq_build_keys(c, T8, Q8, text3, n, keysA, valsA);
-    // radix-sorted prefix: 16 symbols (6 passes) while 16-mers stay selective, else all 21 (8 passes)
-    int ks = c->keySyms ? c->keySyms : (n <= (1ull << 33) ? 16 : 21);
-    bfq_radix_sort(c, keysA, valsA, keysB, valsB, n, ks);
-    c->release(mB);                                     // segment lists reuse the B buffers
-    bfq_refine(c, keysA, valsA, text3, n, ks, c->d_lcp, st);
-    bfq_emit_bwt(c, valsA, n, termOut, c->d_bwt, c->d_qual);
+    bfq_build_keys(c, T8, Q8, text3, n, A);
+    bfq_radix_sort(c, A, B, n);
+    c->release(mB);                                     // the big-segment list reuses the B buffers
+    bfq_refine(c, A, text3, n, c->d_lcp, st);
+    bfq_emit_bwt(c, A, n, termOut, c->d_bwt, c->d_qual);
     c->release(m0);
 }
 

@@ -96,16 +96,42 @@ BFQ_HD u64 bfq_window(const u64 *text3, u64 p)
 }
 BFQ_HD u64 bfq_key_at(const u64 *text3, u64 p) { return bfq_mask_key(bfq_window(text3, p)); }
 
-// ---- sort payload: text position + the (symbol, quality) preceding it --------
-#define BFQ_POS_BITS 40
+// ---- sort record of one suffix: three 32-bit words kept in three arrays (12 bytes per row)
+//   key48   = the suffix's first 16 symbols (top 48 bits of the masked 63-bit window)
+//   payload = text position (37 bits) | preceding symbol code << 37 | its quality << 40   (48 bits)
+//   w0 = key48 >> 16 ;  w1 = (key48 & 0xFFFF) << 16 | payload >> 32 ;  w2 = payload & 0xFFFFFFFF
+// 8-bit radix digits of key48: digits 0,1 live in w1 (bits 16..31), digits 2..5 in w0.
+#define BFQ_KEY_SYMS 16
+#define BFQ_POS_BITS 37
 #define BFQ_POS_MASK ((1ull << BFQ_POS_BITS) - 1ull)
+#define BFQ_LOW3_48 0x0000249249249249ull   // bit 0 of each of the 16 fields of a key48
+BFQ_HD u64 bfq_key48_of(u64 maskedKey63) { return maskedKey63 >> 15; }
 BFQ_HD u64 bfq_pack_val(u64 pos, u32 prevCode, u32 prevQual)
 {
-    return pos | ((u64)prevCode << 40) | ((u64)prevQual << 48);
+    return pos | ((u64)prevCode << 37) | ((u64)(prevQual & 0xFFu) << 40);
 }
 BFQ_HD u64 bfq_val_pos(u64 v) { return v & BFQ_POS_MASK; }
-BFQ_HD u32 bfq_val_code(u64 v) { return (u32)(v >> 40) & 7u; }
-BFQ_HD u32 bfq_val_qual(u64 v) { return (u32)(v >> 48) & 0xFFu; }
+BFQ_HD u32 bfq_val_code(u64 v) { return (u32)(v >> 37) & 7u; }
+BFQ_HD u32 bfq_val_qual(u64 v) { return (u32)(v >> 40) & 0xFFu; }
+BFQ_HD u32 bfq_rec_w0(u64 key48) { return (u32)(key48 >> 16); }
+BFQ_HD u32 bfq_rec_w1(u64 key48, u64 pay) { return ((u32)(key48 & 0xFFFFu) << 16) | (u32)(pay >> 32); }
+BFQ_HD u32 bfq_rec_w2(u64 pay) { return (u32)pay; }
+BFQ_HD u64 bfq_rec_key48(u32 w0, u32 w1) { return ((u64)w0 << 16) | (u64)(w1 >> 16); }
+BFQ_HD u64 bfq_rec_pay(u32 w1, u32 w2) { return ((u64)(w1 & 0xFFFFu) << 32) | (u64)w2; }
+// key48 holds a terminator among its 16 symbols = it is a complete suffix
+BFQ_HD u64 bfq_key48_zero_fields(u64 k) { return ~(k | (k >> 1) | (k >> 2)) & BFQ_LOW3_48; }
+BFQ_HD bool bfq_key48_has_term(u64 k) { return bfq_key48_zero_fields(k) != 0; }
+// common prefix (symbols) of two key48; terminators never match
+BFQ_HD int bfq_key48_lcp(u64 a, u64 b)
+{
+    u64 x = a ^ b;
+    if (x == 0) {
+        u64 z = bfq_key48_zero_fields(a);
+        if (z == 0) return BFQ_KEY_SYMS;
+        return (45 - (63 - bfq_clz64(z))) / 3;
+    }
+    return (bfq_clz64(x) - 16) / 3;
+}
 
 // ---- Illumina 8-level binning, ASCII in/out (bfq_int.cpp:307-319) ------------
 BFQ_HD u32 bfq_bin8(u32 asciiQ)

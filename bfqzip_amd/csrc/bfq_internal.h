@@ -76,7 +76,6 @@ struct bfq_ctx {
     u64 n = 0, N = 0;
 
     // profiling
-    int keySyms = 0;                // 0 = choose per call: radix-sorted prefix length (16 or 21 symbols)
     bool profOn = true;
     std::vector<hipEvent_t> evPool;
     size_t evUsed = 0;
@@ -111,6 +110,9 @@ static inline unsigned bfq_grid(u64 items, u64 perBlock)
     return (unsigned)(b < 1 ? 1 : (b > BFQ_MAX_GRID ? BFQ_MAX_GRID : b));
 }
 
+// the suffix records being sorted: three 32-bit arrays (layout: bfq_common.h)
+struct SortRec { u32 *w0, *w1, *w2; };
+
 // ---- stage entry points (each in its own .hip file) --------------------------------
 // scan: out[i] = sum(in[0..i)) ; T in {u8,u32,u64}; total (device u64) optional
 void bfq_exscan_u8(bfq_ctx *c, const u8 *in, u64 *out, u64 n, u64 *d_total);
@@ -120,12 +122,12 @@ void bfq_exscan_u64(bfq_ctx *c, const u64 *in, u64 *out, u64 n, u64 *d_total);
 // step 1 pieces
 void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 n,
                     u8 *T8, u8 *Q8, u64 *text3, u64 nwords);
-void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u64 *keys, u64 *vals);
-// LSD radix sort of (key,val) pairs on key bits [0,63); result ends in keysA/valsA
-void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, u64 n, int keySyms);
+void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out);
+// LSD radix sort of the records on their 48-bit key; result ends in A
+void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n);
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
-void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n, int keySyms, u16 *lcp, bfq_stats *st);
-void bfq_emit_bwt(bfq_ctx *c, const u64 *vals, u64 n, int termOut, u8 *bwt, u8 *qs);
+void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
+void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs);
 // whole step 1 on device-resident reads; leaves c->d_bwt/d_qual/d_lcp
 void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,
                       int termOut, bfq_stats *st);

@@ -1,25 +1,27 @@
-// k_radix.hip -- stable LSD radix sort of (63-bit key, 64-bit payload) pairs, 8-bit digits.
+// k_radix.hip -- stable LSD radix sort of the suffix records on their 48-bit key (the first 16
+// symbols), 8-bit digits, 6 passes.
 //
 // This is the sort at the heart of the eBWT construction that replaces
-// `gsufsort --bwt --qs` (call site BFQzip.py:184): one pair per read suffix,
-// key = the suffix's first 21 symbols.  Per pass:
+// `gsufsort --bwt --qs` (call site BFQzip.py:184): one record per read suffix.  A record is
+// 12 bytes in three 32-bit arrays (bfq_common.h): the histogram pass reads only the word that
+// holds the pass's digit (4 B/row), the scatter moves 12 B/row each way.  Per pass:
 //   k_radix_hist    : per-workgroup digit counts (per-wave LDS histograms)
 //   exclusive scan  : digit-major table -> global offsets (k_scan.hip)
-//   k_radix_scatter : wave-level match ranking (ballots), per-wave LDS digit
-//                     counters + prefix across waves, pairs staged in LDS in
-//                     tile-sorted order, then written out in coalesced runs.
-// HBM-bound integer work: per pass 8 B/key read (hist) + 16 B read + 16 B written.
+//   k_radix_scatter : wave-level match ranking (ballots), per-wave LDS digit counters +
+//                     prefix across waves, then each of the three words staged through LDS
+//                     in tile-sorted order and written out in coalesced runs.
+// HBM-bound integer work: per pass 4 B/row (hist) + 12 B read + 12 B written.
 #include "bfq_internal.h"
 #include "bfq_device.h"
 
 #define RS_THREADS 256
 #define RS_WAVES 4
-#define RS_ROUNDS 12                                // items per thread
-#define RS_TILE (RS_THREADS * RS_ROUNDS)            // 4096 pairs per tile
+#define RS_ROUNDS 16                                // items per thread
+#define RS_TILE (RS_THREADS * RS_ROUNDS)            // 4096 records per tile
 #define RS_TILES_PER_BLOCK 8
 #define RS_BLOCK_ELEMS ((u64)RS_TILE * RS_TILES_PER_BLOCK)
 
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *__restrict__ keys, u64 n, int shift,
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u32 *__restrict__ dw, u64 n, int shift,
                                                            u32 *__restrict__ hist, u64 nblocks)
 {
     __shared__ u32 wh[RS_WAVES][256];
@@ -30,7 +32,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *__restrict
     u64 end = base + RS_BLOCK_ELEMS;
     if (end > n) end = n;
     for (u64 i = base + threadIdx.x; i < end; i += RS_THREADS) {
-        u32 d = (u32)(keys[i] >> shift) & 255u;
+        u32 d = (dw[i] >> shift) & 255u;
         atomicAdd(&wh[w][d], 1u);
     }
     __syncthreads();
@@ -38,11 +40,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u64 *__restrict
     hist[(u64)d * nblocks + blockIdx.x] = wh[0][d] + wh[1][d] + wh[2][d] + wh[3][d];
 }
 
-__global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(const u64 *__restrict__ kin, const u64 *__restrict__ vin,
-                                                              u64 *__restrict__ kout, u64 *__restrict__ vout, u64 n,
-                                                              int shift, const u64 *__restrict__ blockOff, u64 nblocks)
+// DW = which word carries the digit of this pass (0: w0, 1: w1)
+template <int DW>
+__global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, SortRec out, u64 n, int shift,
+                                                              const u64 *__restrict__ blockOff, u64 nblocks)
 {
-    __shared__ u64 stage[RS_TILE];          // 32 KiB: keys, then payloads
+    __shared__ u32 stage[RS_TILE];          // 16 KiB: one word of the records at a time
+    __shared__ u8 dig[RS_TILE];             // digit of every tile-sorted slot
     __shared__ u32 wcnt[RS_WAVES][256];     // per-wave digit counters -> exclusive prefix across waves
     __shared__ u32 lstart[256];             // first tile-sorted slot of each digit
     __shared__ u64 gbase[256];              // global output cursor of each digit for this workgroup
@@ -61,16 +65,19 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(const u64 *__re
         __syncthreads();
 
         // tile order = (wave, round, lane): wave w owns slots [w*1024, w*1024+1024)
-        u64 k[RS_ROUNDS];
+        u32 a0[RS_ROUNDS], a1[RS_ROUNDS], a2[RS_ROUNDS];
         u32 pk[RS_ROUNDS];                                       // digit << 16 | rank, later digit << 16 | tile slot
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
             u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
-            k[r] = (slot < cnt) ? kin[tbase + slot] : ~0ull;     // padding sorts last (digit 255, tile end)
+            bool ok = slot < cnt;
+            a0[r] = ok ? in.w0[tbase + slot] : 0xFFFFFFFFu;      // padding sorts last (digit 255, tile end)
+            a1[r] = ok ? in.w1[tbase + slot] : 0xFFFFFFFFu;
+            a2[r] = ok ? in.w2[tbase + slot] : 0u;
         }
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
-            u32 d = (u32)(k[r] >> shift) & 255u;
+            u32 d = ((DW ? a1[r] : a0[r]) >> shift) & 255u;
             u64 peers = ~0ull;
 #pragma unroll
             for (int b = 0; b < 8; b++) {
@@ -99,35 +106,36 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(const u64 *__re
         for (int r = 0; r < RS_ROUNDS; r++) {
             u32 d = pk[r] >> 16;
             u32 p = lstart[d] + wcnt[w][d] + (pk[r] & 0xFFFFu);
-            pk[r] = (d << 16) | p;
-            stage[p] = k[r];
+            pk[r] = p;
+            stage[p] = a0[r];
+            dig[p] = (u8)d;
         }
-        // payloads are requested now so that their latency overlaps the key write-out
-        u64 v[RS_ROUNDS];
+        __syncthreads();
+        u64 dst[RS_ROUNDS / 4 * 4];
 #pragma unroll
-        for (int r = 0; r < RS_ROUNDS; r++) {
-            u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
-            v[r] = (slot < cnt) ? vin[tbase + slot] : 0ull;
+        for (int q = 0; q < RS_ROUNDS; q++) {
+            u32 j = q * RS_THREADS + tid;
+            u32 d = dig[j];
+            dst[q] = gbase[d] + (u64)(j - lstart[d]);
+            if (j < cnt) out.w0[dst[q]] = stage[j];
         }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; r++) stage[pk[r]] = a1[r];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < RS_ROUNDS; q++) {
             u32 j = q * RS_THREADS + tid;
-            u64 key = stage[j];
-            u32 d = (u32)(key >> shift) & 255u;
-            if (j < cnt) kout[gbase[d] + (u64)(j - lstart[d])] = key;
+            if (j < cnt) out.w1[dst[q]] = stage[j];
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RS_ROUNDS; r++)                      // the payload's free top byte carries the digit
-            stage[pk[r] & 0xFFFFu] = v[r] | ((u64)(pk[r] >> 16) << 56);
+        for (int r = 0; r < RS_ROUNDS; r++) stage[pk[r]] = a2[r];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < RS_ROUNDS; q++) {
             u32 j = q * RS_THREADS + tid;
-            u64 x = stage[j];
-            u32 d = (u32)(x >> 56);
-            if (j < cnt) vout[gbase[d] + (u64)(j - lstart[d])] = x & 0x00FFFFFFFFFFFFFFull;
+            if (j < cnt) out.w2[dst[q]] = stage[j];
         }
         __syncthreads();
         gbase[tid] += tot;
@@ -135,27 +143,26 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(const u64 *__re
     }
 }
 
-// keySyms = 21: all 63 key bits (8 passes); keySyms = 16: only the first 16 symbols = bits 15..62
-// (6 passes) -- rows equal on them stay in position order and are finished by the refinement.
-void bfq_radix_sort(bfq_ctx *c, u64 *keysA, u64 *valsA, u64 *keysB, u64 *valsB, u64 n, int keySyms)
+// key48 digits: 0,1 in w1 (bits 16..31), 2..5 in w0.  6 passes (even): the result returns to A.
+void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n)
 {
     if (n < 2) return;
     u64 nb = ceil_div(n, RS_BLOCK_ELEMS);
     size_t m = c->mark();
     u32 *hist = c->alloc<u32>(256 * nb);
     u64 *off = c->alloc<u64>(256 * nb);
-    u64 *kin = keysA, *vin = valsA, *kout = keysB, *vout = valsB;
-    const int lowbit = 3 * (BFQ_SYMS_PER_WORD - keySyms);       // 0 or 15
-    const int npass = (63 - lowbit + 7) / 8;                     // 8 or 6: even, so the result returns to A
-    for (int pass = 0; pass < npass; pass++) {
-        int shift = lowbit + pass * 8;
-        KLAUNCH(c, K_RADIX_HIST, 8.0 * (double)n, k_radix_hist, nb, RS_THREADS, (const u64 *)kin, n, shift, hist, nb);
+    SortRec in = A, out = B;
+    for (int pass = 0; pass < 6; pass++) {
+        const int dw = pass < 2 ? 1 : 0;
+        const int shift = pass < 2 ? 16 + 8 * pass : 8 * (pass - 2);
+        const u32 *src = dw ? in.w1 : in.w0;
+        KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist, nb, RS_THREADS, src, n, shift, hist, nb);
         bfq_exscan_u32(c, hist, off, 256 * nb, nullptr);
-        KLAUNCH(c, K_RADIX_SCATTER, 32.0 * (double)n, k_radix_scatter, nb, RS_THREADS, (const u64 *)kin,
-                (const u64 *)vin, kout, vout, n, shift, (const u64 *)off, nb);
-        u64 *t = kin; kin = kout; kout = t;
-        t = vin; vin = vout; vout = t;
+        if (dw)
+            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb);
+        else
+            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<0>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb);
+        SortRec t = in; in = out; out = t;
     }
-    // an even number of passes: result is back in keysA / valsA
     c->release(m);
 }

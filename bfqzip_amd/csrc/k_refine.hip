@@ -26,10 +26,15 @@
 #define LCP_PENDING 0xFFFFu
 #define RF_CHUNK 2048                               // rows per wavefront chunk
 
-// row r starts a segment: its sorted prefix differs from the previous row's, or holds a terminator
-__device__ __forceinline__ bool seg_head(u64 kp, u64 k, int lowbit)
+// row r starts a segment: its 16-symbol key differs from the previous row's, or holds a terminator
+__device__ __forceinline__ bool seg_head(u64 kp, u64 k) { return (k != kp) || bfq_key48_has_term(k); }
+__device__ __forceinline__ u64 rec_key(const SortRec &r, u64 i) { return bfq_rec_key48(r.w0[i], r.w1[i]); }
+__device__ __forceinline__ u64 rec_pay(const SortRec &r, u64 i) { return bfq_rec_pay(r.w1[i], r.w2[i]); }
+// rows of a segment share the key, so its low half can be rewritten from any of them
+__device__ __forceinline__ void rec_set_pay(const SortRec &r, u64 i, u64 pay)
 {
-    return (((k ^ kp) >> lowbit) != 0) || ((bfq_zero_fields(k) >> lowbit) != 0);
+    r.w1[i] = (r.w1[i] & 0xFFFF0000u) | (u32)(pay >> 32);
+    r.w2[i] = (u32)pay;
 }
 
 __device__ __forceinline__ u32 bfq_wave_max32(u32 v)
@@ -43,10 +48,8 @@ __device__ __forceinline__ u32 bfq_wave_max32(u32 v)
     return v;
 }
 
-__global__ __launch_bounds__(256) void k_refine_chunk(const u64 *__restrict__ keys, u64 *__restrict__ vals,
-                                                      u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
-                                                      int lowbit, u32 depth0, u64 *__restrict__ biglist, DevCounters *cnt,
-                                                      u64 nchunks)
+__global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restrict__ lcp, const u64 *__restrict__ text3,
+                                                      u64 n, u64 *__restrict__ biglist, DevCounters *cnt, u64 nchunks)
 {
     // every wavefront works alone on its own chunk (no workgroup barriers): private LDS slices
     __shared__ u64 hb_all[4][RF_CHUNK / 64 + 2];    // head bits of rows [base, base + RF_CHUNK + 128)
@@ -65,10 +68,10 @@ __global__ __launch_bounds__(256) void k_refine_chunk(const u64 *__restrict__ ke
             u64 r = base + (u64)g * 64 + lane;
             bool h = true;                                     // rows past the end close the last segment
             if (r < n) {
-                u64 k = keys[r];
-                u64 kp = r ? keys[r - 1] : 0ull;
-                h = (r == 0) || seg_head(kp, k, lowbit);
-                if (h && g < RF_CHUNK / 64) lcp[r] = r ? (u16)bfq_key_lcp(kp, k) : (u16)0;
+                u64 k = rec_key(rec, r);
+                u64 kp = r ? rec_key(rec, r - 1) : 0ull;
+                h = (r == 0) || seg_head(kp, k);
+                if (h && g < RF_CHUNK / 64) lcp[r] = r ? (u16)bfq_key48_lcp(kp, k) : (u16)0;
             }
             u64 m = __ballot(h);
             if (lane == 0) hb[g] = m;
@@ -128,10 +131,10 @@ __global__ __launch_bounds__(256) void k_refine_chunk(const u64 *__restrict__ ke
                     if ((int)lane >= hp && (int)lane < hp + (int)sz) { myRow = st + (u64)((int)lane - hp); sublo = hp; subhi = hp + (int)sz; seglo = hp; }
                 }
                 const bool act = lane < rows;
-                u64 v = act ? vals[myRow] : 0ull;
+                u64 v = act ? rec_pay(rec, myRow) : 0ull;
                 u32 mylcp = LCP_PENDING;                                            // positional: LCP(row-1,row)
                 u64 unres = __ballot(act);
-                u32 depth = depth0;
+                u32 depth = BFQ_KEY_SYMS;
                 u64 Wn = act ? bfq_key_at(text3, bfq_val_pos(v) + depth) : 0ull;
                 while (unres) {
                     const bool un = (unres >> lane) & 1ull;
@@ -162,7 +165,7 @@ __global__ __launch_bounds__(256) void k_refine_chunk(const u64 *__restrict__ ke
                     depth += BFQ_SYMS_PER_WORD;
                 }
                 if (act) {
-                    vals[myRow] = v;
+                    rec_set_pay(rec, myRow, v);
                     if ((int)lane != seglo) lcp[myRow] = (u16)mylcp;
                 }
                 done += ntake;
@@ -174,38 +177,36 @@ __global__ __launch_bounds__(256) void k_refine_chunk(const u64 *__restrict__ ke
 
 // ---- larger segments: one workgroup each, bitonic network in global memory -------
 // full-suffix order beyond the sorted prefix; ties (identical suffixes) by position
-__device__ bool suffix_less(const u64 *__restrict__ text3, u64 pa, u64 pb, u32 depth0)
+__device__ bool suffix_less(const u64 *__restrict__ text3, u64 pa, u64 pb)
 {
-    for (u32 d = depth0;; d += BFQ_SYMS_PER_WORD) {
+    for (u32 d = BFQ_KEY_SYMS;; d += BFQ_SYMS_PER_WORD) {
         u64 a = bfq_key_at(text3, pa + d), b = bfq_key_at(text3, pb + d);
         if (a != b) return a < b;
         if (bfq_key_has_term(a)) return pa < pb;
     }
 }
-__device__ u32 suffix_lcp(const u64 *__restrict__ text3, u64 pa, u64 pb, u32 depth0)
+__device__ u32 suffix_lcp(const u64 *__restrict__ text3, u64 pa, u64 pb)
 {
-    for (u32 d = depth0;; d += BFQ_SYMS_PER_WORD) {
+    for (u32 d = BFQ_KEY_SYMS;; d += BFQ_SYMS_PER_WORD) {
         u64 a = bfq_key_at(text3, pa + d), b = bfq_key_at(text3, pb + d);
         if (a != b || bfq_key_has_term(a)) return d + (u32)bfq_key_lcp(a, b);
     }
 }
 
-__device__ __forceinline__ void big_step(u64 *a, u64 g, u64 j, const u64 *__restrict__ text3, u32 depth0)
+__device__ __forceinline__ void big_step(const SortRec &rec, u64 s, u64 g, u64 j, const u64 *__restrict__ text3)
 {
     for (u64 i = threadIdx.x; i < g; i += 256) {
         u64 l = i ^ j;
         if (l > i && l < g) {                      // rows >= g are a virtual +inf padding
-            u64 va = a[i], vb = a[l];
-            if (suffix_less(text3, bfq_val_pos(vb), bfq_val_pos(va), depth0)) { a[i] = vb; a[l] = va; }
+            u64 va = rec_pay(rec, s + i), vb = rec_pay(rec, s + l);
+            if (suffix_less(text3, bfq_val_pos(vb), bfq_val_pos(va))) { rec_set_pay(rec, s + i, vb); rec_set_pay(rec, s + l, va); }
         }
     }
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ biglist, const DevCounters *cnt,
-                                                    const u64 *__restrict__ keys, u64 *__restrict__ vals,
-                                                    u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
-                                                    int lowbit, u32 depth0)
+__global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ biglist, const DevCounters *cnt, SortRec rec,
+                                                    u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n)
 {
     __shared__ u64 shEnd;
     const u64 nbig = cnt->bigCount;
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
         __syncthreads();
         for (u64 b0 = s + 1;; b0 += 256) {             // first head after s = end of the segment
             u64 i = b0 + threadIdx.x;
-            bool h = (i >= n) ? true : seg_head(keys[i - 1], keys[i], lowbit);
+            bool h = (i >= n) ? true : seg_head(rec_key(rec, i - 1), rec_key(rec, i));
             if (h) atomicMin(&shEnd, i);
             __syncthreads();
             bool done = (shEnd != ~0ull);
@@ -224,50 +225,47 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
             if (done) break;                           // uniform
         }
         const u64 g = shEnd - s;
-        u64 *a = vals + s;
         u64 P = 1;
         while (P < g) P <<= 1;
         // bitonic network with ascending comparators only: flip (i <-> i^(k-1)) then
         // disperse (i <-> i^j, j = k/4 .. 1); the +inf padding beyond g never moves
         for (u64 k = 2; k <= P; k <<= 1) {
-            big_step(a, g, k - 1, text3, depth0);
-            for (u64 j = k >> 2; j >= 1; j >>= 1) big_step(a, g, j, text3, depth0);
+            big_step(rec, s, g, k - 1, text3);
+            for (u64 j = k >> 2; j >= 1; j >>= 1) big_step(rec, s, g, j, text3);
         }
         for (u64 i = 1 + threadIdx.x; i < g; i += 256)
-            lcp[s + i] = (u16)suffix_lcp(text3, bfq_val_pos(a[i - 1]), bfq_val_pos(a[i]), depth0);
+            lcp[s + i] = (u16)suffix_lcp(text3, bfq_val_pos(rec_pay(rec, s + i - 1)), bfq_val_pos(rec_pay(rec, s + i)));
     }
 }
 
 // eBWT byte and permuted quality of every row, from the sort payload
-__global__ __launch_bounds__(256) void k_emit_bwt(const u64 *__restrict__ vals, u64 n, u32 termOut, u8 *__restrict__ bwt,
-                                                  u8 *__restrict__ qs)
+__global__ __launch_bounds__(256) void k_emit_bwt(SortRec rec, u64 n, u32 termOut, u8 *__restrict__ bwt, u8 *__restrict__ qs)
 {
     for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
-        u64 v = vals[r];
+        u64 v = rec_pay(rec, r);
         u32 code = bfq_val_code(v);
         bwt[r] = code ? bfq_code_sym(code) : (u8)termOut;
         qs[r] = (u8)bfq_val_qual(v);
     }
 }
 
-void bfq_refine(bfq_ctx *c, const u64 *keys, u64 *vals, const u64 *text3, u64 n, int keySyms, u16 *lcp, bfq_stats *st)
+void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st)
 {
     (void)st;
     if (!n) return;
-    const int lowbit = 3 * (BFQ_SYMS_PER_WORD - keySyms);
     size_t m = c->mark();
     u64 *biglist = c->alloc<u64>(n / 65 + 2);
     u64 nchunks = ceil_div(n, RF_CHUNK);
-    KLAUNCH(c, K_REFINE_WAVE, 26.0 * (double)n, k_refine_chunk, bfq_grid(nchunks, 4), 256, keys, vals, lcp, text3, n, lowbit,
-            (u32)keySyms, biglist, c->d_cnt, nchunks);
+    KLAUNCH(c, K_REFINE_WAVE, 26.0 * (double)n, k_refine_chunk, bfq_grid(nchunks, 4), 256, rec, lcp, text3, n, biglist,
+            c->d_cnt, nchunks);
     // the list length stays on the device: a fixed grid strides over it (usually empty)
-    KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, 1024, 256, (const u64 *)biglist, (const DevCounters *)c->d_cnt, keys, vals,
-            lcp, text3, n, lowbit, (u32)keySyms);
+    KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, 1024, 256, (const u64 *)biglist, (const DevCounters *)c->d_cnt, rec, lcp,
+            text3, n);
     c->release(m);
 }
 
-void bfq_emit_bwt(bfq_ctx *c, const u64 *vals, u64 n, int termOut, u8 *bwt, u8 *qs)
+void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs)
 {
     if (!n) return;
-    KLAUNCH(c, K_EMIT, 10.0 * (double)n, k_emit_bwt, bfq_grid(n, 256), 256, vals, n, (u32)(termOut & 0xFF), bwt, qs);
+    KLAUNCH(c, K_EMIT, 10.0 * (double)n, k_emit_bwt, bfq_grid(n, 256), 256, rec, n, (u32)(termOut & 0xFF), bwt, qs);
 }

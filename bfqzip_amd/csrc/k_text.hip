@@ -48,10 +48,9 @@ __global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n,
     }
 }
 
-// one thread per suffix: masked 21-symbol key + payload (position, previous symbol, its quality)
+// one thread per suffix: 16-symbol key + payload (position, previous symbol, its quality) as a 12-byte record
 __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, const u8 *__restrict__ Q8,
-                                                    const u64 *__restrict__ text3, u64 n, u64 *__restrict__ keys,
-                                                    u64 *__restrict__ vals)
+                                                    const u64 *__restrict__ text3, u64 n, SortRec out)
 {
     for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (u64)gridDim.x * blockDim.x) {
         u32 pc = 0, pq = (u32)'#';
@@ -59,8 +58,11 @@ __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, c
             pc = T8[p - 1];
             if (pc) pq = Q8[p - 1];
         }
-        keys[p] = bfq_key_at(text3, p);
-        vals[p] = bfq_pack_val(p, pc, pq);
+        u64 k48 = bfq_key48_of(bfq_key_at(text3, p));
+        u64 pay = bfq_pack_val(p, pc, pq);
+        out.w0[p] = bfq_rec_w0(k48);
+        out.w1[p] = bfq_rec_w1(k48, pay);
+        out.w2[p] = bfq_rec_w2(pay);
     }
 }
 
@@ -77,8 +79,8 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
             nwords);
 }
 
-void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u64 *keys, u64 *vals)
+void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out)
 {
     if (!n) return;
-    KLAUNCH(c, K_KEYS, 18.5 * (double)n, k_build_keys, bfq_grid(n, 256), 256, T8, Q8, text3, n, keys, vals);
+    KLAUNCH(c, K_KEYS, 14.5 * (double)n, k_build_keys, bfq_grid(n, 256), 256, T8, Q8, text3, n, out);
 }
