@@ -261,10 +261,10 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
     u64 *text3 = c->alloc<u64>(nwords);
     SortRec A, B;
-    A.w0 = c->alloc<u32>(n + 16); A.w1 = c->alloc<u32>(n + 16); A.w2 = c->alloc<u32>(n + 16);
+    A.w0 = c->alloc<u32>(n + 16); A.w12 = c->alloc<u64>(n + 16);
     size_t mB = c->mark();
-    B.w0 = c->alloc<u32>(n + 16); B.w1 = c->alloc<u32>(n + 16); B.w2 = c->alloc<u32>(n + 16);
-    u8 *T8 = (u8 *)B.w0, *Q8 = (u8 *)B.w1;             // dead before the sort's first scatter
+    B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16);
+    u8 *T8 = (u8 *)B.w0, *Q8 = (u8 *)B.w12;             // dead before the sort's first scatter
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
     bfq_build_keys(c, T8, Q8, text3, n, A);
     bfq_radix_sort(c, A, B, n);

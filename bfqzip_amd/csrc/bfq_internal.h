@@ -111,7 +111,7 @@ static inline unsigned bfq_grid(u64 items, u64 perBlock)
 }
 
 // the suffix records being sorted: three 32-bit arrays (layout: bfq_common.h)
-struct SortRec { u32 *w0, *w1, *w2; };
+struct SortRec { u32 *w0; u64 *w12; };   // w12 = w2 << 32 | w1
 
 // ---- stage entry points (each in its own .hip file) --------------------------------
 // scan: out[i] = sum(in[0..i)) ; T in {u8,u32,u64}; total (device u64) optional

@@ -16,12 +16,13 @@
 
 #define RS_THREADS 256
 #define RS_WAVES 4
-#define RS_ROUNDS 16                                // items per thread
-#define RS_TILE (RS_THREADS * RS_ROUNDS)            // 4096 records per tile
+#define RS_ROUNDS 12                                // items per thread
+#define RS_TILE (RS_THREADS * RS_ROUNDS)            // 3072 records per tile
 #define RS_TILES_PER_BLOCK 8
 #define RS_BLOCK_ELEMS ((u64)RS_TILE * RS_TILES_PER_BLOCK)
 
-__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u32 *__restrict__ dw, u64 n, int shift,
+template <class T>
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const T *__restrict__ dw, u64 n, int shift,
                                                            u32 *__restrict__ hist, u64 nblocks)
 {
     __shared__ u32 wh[RS_WAVES][256];
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const u32 *__restrict
     u64 end = base + RS_BLOCK_ELEMS;
     if (end > n) end = n;
     for (u64 i = base + threadIdx.x; i < end; i += RS_THREADS) {
-        u32 d = (dw[i] >> shift) & 255u;
+        u32 d = (u32)(dw[i] >> shift) & 255u;
         atomicAdd(&wh[w][d], 1u);
     }
     __syncthreads();
@@ -45,7 +46,7 @@ template <int DW>
 __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, SortRec out, u64 n, int shift,
                                                               const u64 *__restrict__ blockOff, u64 nblocks)
 {
-    __shared__ u32 stage[RS_TILE];          // 16 KiB: one word of the records at a time
+    __shared__ u64 stage[RS_TILE];          // w0, then the (w1,w2) pair of the records
     __shared__ u8 dig[RS_TILE];             // digit of every tile-sorted slot
     __shared__ u32 wcnt[RS_WAVES][256];     // per-wave digit counters -> exclusive prefix across waves
     __shared__ u32 lstart[256];             // first tile-sorted slot of each digit
@@ -72,8 +73,9 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, Sor
             u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
             bool ok = slot < cnt;
             a0[r] = ok ? in.w0[tbase + slot] : 0xFFFFFFFFu;      // padding sorts last (digit 255, tile end)
-            a1[r] = ok ? in.w1[tbase + slot] : 0xFFFFFFFFu;
-            a2[r] = ok ? in.w2[tbase + slot] : 0u;
+            u64 x12 = ok ? in.w12[tbase + slot] : 0xFFFFFFFFull;
+            a1[r] = (u32)x12;
+            a2[r] = (u32)(x12 >> 32);
         }
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
@@ -107,35 +109,26 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, Sor
             u32 d = pk[r] >> 16;
             u32 p = lstart[d] + wcnt[w][d] + (pk[r] & 0xFFFFu);
             pk[r] = p;
-            stage[p] = a0[r];
+            stage[p] = (u64)a0[r];
             dig[p] = (u8)d;
         }
         __syncthreads();
-        u64 dst[RS_ROUNDS / 4 * 4];
+        u64 dst[RS_ROUNDS];
 #pragma unroll
         for (int q = 0; q < RS_ROUNDS; q++) {
             u32 j = q * RS_THREADS + tid;
             u32 d = dig[j];
             dst[q] = gbase[d] + (u64)(j - lstart[d]);
-            if (j < cnt) out.w0[dst[q]] = stage[j];
+            if (j < cnt) out.w0[dst[q]] = (u32)stage[j];
         }
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < RS_ROUNDS; r++) stage[pk[r]] = a1[r];
+        for (int r = 0; r < RS_ROUNDS; r++) stage[pk[r]] = ((u64)a2[r] << 32) | a1[r];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < RS_ROUNDS; q++) {
             u32 j = q * RS_THREADS + tid;
-            if (j < cnt) out.w1[dst[q]] = stage[j];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int r = 0; r < RS_ROUNDS; r++) stage[pk[r]] = a2[r];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < RS_ROUNDS; q++) {
-            u32 j = q * RS_THREADS + tid;
-            if (j < cnt) out.w2[dst[q]] = stage[j];
+            if (j < cnt) out.w12[dst[q]] = stage[j];
         }
         __syncthreads();
         gbase[tid] += tot;
@@ -155,8 +148,10 @@ void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n)
     for (int pass = 0; pass < 6; pass++) {
         const int dw = pass < 2 ? 1 : 0;
         const int shift = pass < 2 ? 16 + 8 * pass : 8 * (pass - 2);
-        const u32 *src = dw ? in.w1 : in.w0;
-        KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist, nb, RS_THREADS, src, n, shift, hist, nb);
+        if (dw)
+            KLAUNCH(c, K_RADIX_HIST, 8.0 * (double)n, k_radix_hist<u64>, nb, RS_THREADS, (const u64 *)in.w12, n, shift, hist, nb);
+        else
+            KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist<u32>, nb, RS_THREADS, (const u32 *)in.w0, n, shift, hist, nb);
         bfq_exscan_u32(c, hist, off, 256 * nb, nullptr);
         if (dw)
             KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb);

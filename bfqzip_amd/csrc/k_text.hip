@@ -61,8 +61,7 @@ __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, c
         u64 k48 = bfq_key48_of(bfq_key_at(text3, p));
         u64 pay = bfq_pack_val(p, pc, pq);
         out.w0[p] = bfq_rec_w0(k48);
-        out.w1[p] = bfq_rec_w1(k48, pay);
-        out.w2[p] = bfq_rec_w2(pay);
+        out.w12[p] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(k48, pay);
     }
 }
 
