@@ -37,17 +37,6 @@ __device__ __forceinline__ void rec_set_pay(const SortRec &r, u64 i, u64 pay)
     r.w12[i] = ((u64)(u32)pay << 32) | w1;
 }
 
-__device__ __forceinline__ u32 bfq_wave_max32(u32 v)
-{
-    u32 lane = bfq_lane();
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-        u32 o = (u32)__builtin_amdgcn_ds_bpermute((int)((lane ^ d) << 2), (int)v);
-        v = o > v ? o : v;
-    }
-    return v;
-}
-
 __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restrict__ lcp, const u64 *__restrict__ text3,
                                                       u64 n, u64 *__restrict__ biglist, DevCounters *cnt, u64 nchunks)
 {
@@ -67,9 +56,10 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
         for (u32 g = 0; g < RF_CHUNK / 64 + 2; g++) {
             u64 r = base + (u64)g * 64 + lane;
             bool h = true;                                     // rows past the end close the last segment
+            u64 k = (r < n) ? rec_key(rec, r) : 0ull;
+            u64 kp = bfq_from_prev_lane(k);                    // key of row r-1: the previous lane's, one extra load for lane 0
+            if (lane == 0 && r && r < n) kp = rec_key(rec, r - 1);
             if (r < n) {
-                u64 k = rec_key(rec, r);
-                u64 kp = r ? rec_key(rec, r - 1) : 0ull;
                 h = (r == 0) || seg_head(kp, k);
                 if (h && g < RF_CHUNK / 64) lcp[r] = r ? (u16)bfq_key48_lcp(kp, k) : (u16)0;
             }
@@ -134,22 +124,31 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                 u64 v = act ? rec_pay(rec, myRow) : 0ull;
                 u32 mylcp = LCP_PENDING;                                            // positional: LCP(row-1,row)
                 u64 unres = __ballot(act);
+                u64 curHeads = ~0ull;                                               // head lanes of the current sub-segments
+                curHeads = __ballot(!act || (int)lane == sublo);
                 u32 depth = BFQ_KEY_SYMS;
                 u64 Wn = act ? bfq_key_at(text3, bfq_val_pos(v) + depth) : 0ull;
                 while (unres) {
                     const bool un = (unres >> lane) & 1ull;
                     u64 W = Wn;
                     Wn = (un && !bfq_key_has_term(W)) ? bfq_key_at(text3, bfq_val_pos(v) + depth + BFQ_SYMS_PER_WORD) : 0ull;
-                    u32 maxsz = bfq_wave_max32(un ? (u32)(subhi - sublo) : 0u);
-                    int c = 0;
-                    u64 Wu = W, Wd = W;                                             // W of lane+d / lane-d, shifted one lane per step
+                    // longest open sub-segment = longest run of non-head lanes + 1 (scalar bit trick on the head mask)
+                    u32 maxsz = 1;
+                    for (u64 run = ~curHeads; run; run &= run >> 1) maxsz++;
+                    // stable rank of a row inside its sub-segment = #(later rows with a smaller word)
+                    // + #(earlier rows with a word <= its own).  Only the first kind is compared
+                    // (W of lane+d arrives by a one-lane DPP shift per step); the ballot of those
+                    // comparisons, read at lane-d, gives the second kind by complement.
+                    int c = 0, inv = 0;
+                    u64 Wu = W;
                     for (u32 d = 1; d < maxsz; d++) {
-                        int up = (int)lane + (int)d, dn = (int)lane - (int)d;
                         Wu = bfq_from_next_lane(Wu);
-                        Wd = bfq_from_prev_lane(Wd);
-                        if (un && up < subhi && Wu < W) c++;
-                        if (un && dn >= sublo && Wd <= W) c++;
+                        bool f = un && ((int)lane + (int)d < subhi) && (Wu < W);     // row lane+d sorts before me
+                        u64 fb = __ballot(f);
+                        c += f ? 1 : 0;
+                        if (lane >= d) inv += (int)((fb >> (lane - d)) & 1ull);      // I sort before row lane-d
                     }
+                    c += ((int)lane - sublo) - inv;
                     int np = un ? sublo + c : (int)lane;
                     v = bfq_permute64(v, np);
                     W = bfq_permute64(W, np);
@@ -158,6 +157,7 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                     bool newhead = un && ((int)lane == sublo || W != Wprev || bfq_key_has_term(W));
                     if (un && (int)lane != sublo && newhead) mylcp = depth + (u32)bfq_key_lcp(Wprev, W);
                     u64 heads = __ballot(newhead || !un);
+                    curHeads = heads;
                     sublo = 63 - __clzll((long long)(heads & le));
                     u64 above = heads & ~le;
                     subhi = above ? __builtin_ctzll(above) : 64;
@@ -256,7 +256,9 @@ void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_
     size_t m = c->mark();
     u64 *biglist = c->alloc<u64>(n / 65 + 2);
     u64 nchunks = ceil_div(n, RF_CHUNK);
-    KLAUNCH(c, K_REFINE_WAVE, 26.0 * (double)n, k_refine_chunk, bfq_grid(nchunks, 4), 256, rec, lcp, text3, n, biglist,
+    // remaining packed suffix read once (3(L+1)/16 B) + order 8 B + LCP 1 B per row
+    const double lavg = c->N ? (double)(n - c->N) / (double)c->N : 0.0;
+    KLAUNCH(c, K_REFINE_WAVE, (3.0 * (lavg + 1.0) / 16.0 + 9.0) * (double)n, k_refine_chunk, bfq_grid(nchunks, 4), 256, rec, lcp, text3, n, biglist,
             c->d_cnt, nchunks);
     // the list length stays on the device: a fixed grid strides over it (usually empty)
     KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, 1024, 256, (const u64 *)biglist, (const DevCounters *)c->d_cnt, rec, lcp,
