@@ -37,6 +37,30 @@ __device__ __forceinline__ void rec_set_pay(const SortRec &r, u64 i, u64 pay)
     r.w12[i] = ((u64)(u32)pay << 32) | w1;
 }
 
+// payload <-> working form: word index (34 bits) | 3*offset (6 bits) << 34 | code << 40 | quality << 43 of p + 16
+__device__ __forceinline__ u64 wo_from_pay(u64 pay)
+{
+    u64 p = bfq_val_pos(pay) + BFQ_KEY_SYMS;
+    u64 w = p / BFQ_SYMS_PER_WORD;
+    u64 o3 = (p - w * BFQ_SYMS_PER_WORD) * 3ull;
+    return w | (o3 << 34) | ((u64)bfq_val_code(pay) << 40) | ((u64)bfq_val_qual(pay) << 43);
+}
+__device__ __forceinline__ u64 wo_to_pay(u64 v)
+{
+    u64 w = v & ((1ull << 34) - 1ull), o3 = (v >> 34) & 63ull;
+    u64 p = w * BFQ_SYMS_PER_WORD + o3 / 3ull - BFQ_KEY_SYMS;
+    return bfq_pack_val(p, (u32)(v >> 40) & 7u, (u32)(v >> 43) & 0xFFu);
+}
+// masked 21-symbol window `round` words further along the suffix
+__device__ __forceinline__ u64 wo_key(const u64 *__restrict__ text3, u64 v, u32 round)
+{
+    u64 w = (v & ((1ull << 34) - 1ull)) + round;
+    u32 o = (u32)(v >> 34) & 63u;
+    u64 hi = (text3[w] << o) & BFQ_M63;
+    u64 lo = o ? (text3[w + 1] >> (63u - o)) : 0ull;
+    return bfq_mask_key(hi | lo);
+}
+
 __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restrict__ lcp, const u64 *__restrict__ text3,
                                                       u64 n, u64 *__restrict__ biglist, DevCounters *cnt, u64 nchunks)
 {
@@ -121,17 +145,20 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                     if ((int)lane >= hp && (int)lane < hp + (int)sz) { myRow = st + (u64)((int)lane - hp); sublo = hp; subhi = hp + (int)sz; seglo = hp; }
                 }
                 const bool act = lane < rows;
-                u64 v = act ? rec_pay(rec, myRow) : 0ull;
+                // working form of the payload: word index and bit offset of text position p + 16 instead of p,
+                // so that the word of every later round (+21 symbols = +1 word) needs no division
+                u64 v = act ? wo_from_pay(rec_pay(rec, myRow)) : 0ull;
                 u32 mylcp = LCP_PENDING;                                            // positional: LCP(row-1,row)
                 u64 unres = __ballot(act);
                 u64 curHeads = ~0ull;                                               // head lanes of the current sub-segments
                 curHeads = __ballot(!act || (int)lane == sublo);
                 u32 depth = BFQ_KEY_SYMS;
-                u64 Wn = act ? bfq_key_at(text3, bfq_val_pos(v) + depth) : 0ull;
+                u32 round = 0;
+                u64 Wn = act ? wo_key(text3, v, 0) : 0ull;
                 while (unres) {
                     const bool un = (unres >> lane) & 1ull;
                     u64 W = Wn;
-                    Wn = (un && !bfq_key_has_term(W)) ? bfq_key_at(text3, bfq_val_pos(v) + depth + BFQ_SYMS_PER_WORD) : 0ull;
+                    Wn = (un && !bfq_key_has_term(W)) ? wo_key(text3, v, round + 1) : 0ull;
                     // longest open sub-segment = longest run of non-head lanes + 1 (scalar bit trick on the head mask)
                     u32 maxsz = 1;
                     for (u64 run = ~curHeads; run; run &= run >> 1) maxsz++;
@@ -163,9 +190,10 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                     subhi = above ? __builtin_ctzll(above) : 64;
                     unres = __ballot(un && (subhi - sublo > 1));
                     depth += BFQ_SYMS_PER_WORD;
+                    round++;
                 }
                 if (act) {
-                    rec_set_pay(rec, myRow, v);
+                    rec_set_pay(rec, myRow, wo_to_pay(v));
                     if ((int)lane != seglo) lcp[myRow] = (u16)mylcp;
                 }
                 done += ntake;
