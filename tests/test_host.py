@@ -72,3 +72,12 @@ def test_synthetic_generator_is_seeded_and_shaped():
     bv, qv, rv = api.synth_host(spv)
     lens = np.diff(rv.astype(np.int64))
     assert lens.min() >= 20 and lens.max() <= 70 and len(bv) == int(rv[-1])
+
+
+def test_shared_host_device_helpers(tmp_path):
+    """bfq_common.h (key windows, terminator masking, key LCP, sort records, binning) compiled for the host."""
+    import subprocess
+    exe = str(tmp_path / "test_common")
+    subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cxx", "test_common.cpp")])
+    r = subprocess.run([exe], stdout=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
