@@ -1,0 +1,44 @@
+"""GPU test of the sharded path: BFQzip_parallel's split, one process per rank (gloo here, both
+ranks on the single GPU of the test box), the real engine per block, ordered gather on rank 0.
+Expected md5s: the reference's own BFQzip_parallel.py runs."""
+import hashlib, os, sys
+import pytest
+from tests import util
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, t, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from bfqzip_amd import api, fastq, parallel
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = api.Engine(0, m=5)
+    def run(b, qq, r):
+        ob, oq, st = eng.run_reads(b, qq, r)
+        return ob, oq
+    b, qq, r, h, *_ = util.golden_set("example")
+    res = parallel.run_blocks(run, b, qq, r, t, dist=dist)
+    if rank == 0:
+        q.put(hashlib.md5(fastq.format_fastq(res[0], res[1], r)).hexdigest())
+    dist.barrier()
+    eng.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("t,md5", [(2, "d2aac3c45dda67ec3f769273ea6a5568"), (8, "4ada980195fd8d6fb206408c4f892bc6")])
+def test_two_ranks_real_engine(t, md5):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29700 + (os.getpid() % 2000) + t
+    ps = [ctx.Process(target=_worker, args=(rk, 2, port, t, q)) for rk in range(2)]
+    for p in ps:
+        p.start()
+    got = q.get(timeout=300)
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got == md5
