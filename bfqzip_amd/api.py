@@ -107,6 +107,47 @@ class Engine:
                                              d_out_quals, C.byref(st)))
         return st.as_dict()
 
+    # ---- FASTQ text in / out, parsed and formatted on the GPU
+    def fastq_build_ebwt(self, text, term_out=ord("#"), want_lcp=True):
+        """gsufsort / eGap on the bytes of a FASTQ file -> (bwt, qs, lcp16)."""
+        buf = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+        cap = len(buf) // 2 + 1
+        bwt = np.empty(cap, np.uint8); qs = np.empty(cap, np.uint8)
+        lcp = np.empty(cap, np.uint16) if want_lcp else None
+        n = C.c_uint64(0); N = C.c_uint64(0)
+        self._ck(self.L.bfq_fastq_build_ebwt(self.h, _ptr(buf), len(buf), term_out, _ptr(bwt), _ptr(qs), _ptr(lcp), cap,
+                                             C.byref(n), C.byref(N)))
+        return bwt[:n.value], qs[:n.value], (lcp[:n.value] if want_lcp else None)
+
+    def fastq_run(self, text, keep_headers=False):
+        """The whole path on the bytes of a FASTQ file -> (smoothed FASTQ bytes, stats)."""
+        buf = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+        out = np.empty(len(buf) + 16, np.uint8)
+        ol = C.c_uint64(0)
+        st = _lib.Stats()
+        self._ck(self.L.bfq_fastq_run(self.h, _ptr(buf), len(buf), 1 if keep_headers else 0, _ptr(out), len(out),
+                                      C.byref(ol), C.byref(st)))
+        return out[:ol.value].tobytes(), st.as_dict()
+
+    def smooth_invert_fastq(self, bwt, qs, lcp=None, headers=None):
+        """bfq_int / bfq_ext writing the FASTQ text; headers = bytes of the -H file or None."""
+        bwt = np.ascontiguousarray(bwt, np.uint8); qs = np.ascontiguousarray(qs, np.uint8)
+        n = len(bwt)
+        N = C.c_uint64(0)
+        self.L.bfq_count_reads(_ptr(bwt), n, self.params.term & 0xFF, C.byref(N))
+        N = N.value
+        lcp_bytes = 0
+        if lcp is not None:
+            lcp = np.ascontiguousarray(lcp); lcp_bytes = lcp.dtype.itemsize
+        hb = np.frombuffer(headers, np.uint8) if headers is not None else None
+        cap = int(self.L.bfq_fastq_out_bound(n - N, N, len(hb) if hb is not None else 0)) + 16
+        out = np.empty(cap, np.uint8)
+        ol = C.c_uint64(0)
+        st = _lib.Stats()
+        self._ck(self.L.bfq_smooth_invert_fastq(self.h, _ptr(bwt), _ptr(qs), _ptr(lcp), lcp_bytes, n, _ptr(hb),
+                                                len(hb) if hb is not None else 0, _ptr(out), cap, C.byref(ol), C.byref(st)))
+        return out[:ol.value].tobytes(), st.as_dict()
+
     def fetch_ebwt(self, n):
         bwt = np.empty(n, np.uint8); qs = np.empty(n, np.uint8); lcp = np.empty(n, np.uint16)
         self._ck(self.L.bfq_fetch_ebwt(self.h, _ptr(bwt), _ptr(qs), _ptr(lcp)))

@@ -16,7 +16,7 @@
 const char *const BFQ_KERNEL_NAMES[K_NUM] = {
     "k_text_from_reads", "k_pack3", "k_build_keys", "k_radix_hist", "k_scan", "k_radix_scatter", "k_seg_flags",
     "k_seg_compact", "k_refine_chunk", "k_refine_big", "k_emit_bwt", "k_lf_count", "k_lf_build", "k_lcp_flags",
-    "k_cluster_compact", "k_cluster", "k_invert_count", "k_invert", "k_synth", "misc"};
+    "k_cluster_compact", "k_cluster", "k_invert_count", "k_invert", "k_synth", "k_fastq", "misc"};
 
 static thread_local std::string g_createErr;
 
@@ -381,11 +381,12 @@ __global__ __launch_bounds__(256) void k_compare_bytes(const u8 *__restrict__ a,
     if (bad) atomicAdd(&cnt->mismatch, 1ull);
 }
 
-extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp,
-                                 int lcp_bytes, uint64_t n, uint8_t *h_out_bases, uint8_t *h_out_quals,
-                                 uint64_t *h_out_read_off, bfq_stats *st)
+// steps 2-4 on a host-resident eBWT; leaves the smoothed reads on the device (arena)
+struct SmoothOut { u8 *ob, *oq; u64 *roff; u64 N, total; };
+static void smooth_invert_core(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp, int lcp_bytes,
+                               uint64_t n, size_t extraWs, bfq_stats *st, SmoothOut *res)
 {
-    return guarded(c, [&] {
+    {
         if (st) memset(st, 0, sizeof *st);
         if (n && (!h_bwt || !h_bwtqs)) throw BfqError{BFQ_E_ARG, "null eBWT"};
         if (h_lcp && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
@@ -394,7 +395,7 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
         u64 N = Nr;
         if (n && N == 0) throw BfqError{BFQ_E_NOT_EBWT, "no terminator in the eBWT"};
         u64 total = n - N;
-        c->reserve(ws_need(n, N, 6 * (n + 256) + 16 * (N + 64)));
+        c->reserve(ws_need(n, N, 6 * (n + 256) + 16 * (N + 64) + extraWs));
         c->zeroCounters();
         u8 *in_bwt = c->alloc<u8>(n + 64), *in_qs = c->alloc<u8>(n + 64);
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
@@ -444,11 +445,123 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
             (void)m;   // rb/rq stay allocated below the step-1 arrays; the arena is reset per call
         }
         steps234_device(c, d_roff, ob, oq);
-        if (total) {
-            HIP_CHECK(hipMemcpyAsync(h_out_bases, ob, total, hipMemcpyDeviceToHost, c->stream));
-            HIP_CHECK(hipMemcpyAsync(h_out_quals, oq, total, hipMemcpyDeviceToHost, c->stream));
+        res->ob = ob; res->oq = oq; res->roff = d_roff; res->N = N; res->total = total;
+    }
+}
+
+extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp,
+                                 int lcp_bytes, uint64_t n, uint8_t *h_out_bases, uint8_t *h_out_quals,
+                                 uint64_t *h_out_read_off, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        SmoothOut r;
+        smooth_invert_core(c, h_bwt, h_bwtqs, h_lcp, lcp_bytes, n, 0, st, &r);
+        if (r.total) {
+            HIP_CHECK(hipMemcpyAsync(h_out_bases, r.ob, r.total, hipMemcpyDeviceToHost, c->stream));
+            HIP_CHECK(hipMemcpyAsync(h_out_quals, r.oq, r.total, hipMemcpyDeviceToHost, c->stream));
         }
-        HIP_CHECK(hipMemcpyAsync(h_out_read_off, d_roff, 8 * (N + 1), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpyAsync(h_out_read_off, r.roff, 8 * (r.N + 1), hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+        fill_stats(c, st);
+    });
+}
+
+// ---------------------------------------------------------------- FASTQ text in / out
+// The FASTQ text lives outside the arena (its record count sizes the arena): uploaded first, lines
+// counted on the device, then the workspace is reserved for the real N.
+struct DevText {
+    u8 *p = nullptr;
+    ~DevText() { if (p) (void)hipFree(p); }
+};
+u64 bfq_fastq_count_lines(bfq_ctx *c, const u8 *d_buf, u64 len);   // k_fastq.hip
+static void fastq_upload_and_reserve(bfq_ctx *c, const uint8_t *h_fastq, u64 len, DevText &t)
+{
+    if (hipMalloc((void **)&t.p, len + 64) != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; throw BfqError{BFQ_E_NOMEM, "device buffer for the FASTQ text"}; }
+    if (len) HIP_CHECK(hipMemcpyAsync(t.p, h_fastq, len, hipMemcpyHostToDevice, c->stream));
+    c->reserve(16 * (len / 4096 + 16) + (64u << 20));
+    u64 nlines = bfq_fastq_count_lines(c, t.p, len);
+    u64 N = nlines / 4 + 1;
+    u64 nb = len / 2 + 1;                                       // rows <= bytes / 2
+    c->reserve(ws_need(nb, N, 3 * (len + 4096) + 128 * (N + 64) + 8 * (nlines + 64)));
+}
+
+extern "C" uint64_t bfq_fastq_out_bound(uint64_t total_bases, uint64_t n_reads, uint64_t header_bytes)
+{
+    return 2 * total_bases + 5 * n_reads + (header_bytes ? header_bytes : n_reads);
+}
+
+extern "C" int bfq_fastq_build_ebwt(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int term_out, uint8_t *h_bwt,
+                                    uint8_t *h_bwtqs, uint16_t *h_lcp16, uint64_t cap_rows, uint64_t *n_rows,
+                                    uint64_t *n_reads)
+{
+    return guarded(c, [&] {
+        DevText txt;
+        fastq_upload_and_reserve(c, h_fastq, len, txt);
+        c->zeroCounters();
+        u8 *d_fq = txt.p;
+        DevFastq fq;
+        bfq_fastq_parse(c, d_fq, len, &fq);
+        u64 n = fq.total + fq.N;
+        if (n_rows) *n_rows = n;
+        if (n_reads) *n_reads = fq.N;
+        if (n > cap_rows) throw BfqError{BFQ_E_ARG, "output buffers smaller than the eBWT (need total bases + reads entries)"};
+        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, term_out, nullptr);
+        if (h_bwt) HIP_CHECK(hipMemcpyAsync(h_bwt, c->d_bwt, n, hipMemcpyDeviceToHost, c->stream));
+        if (h_bwtqs) HIP_CHECK(hipMemcpyAsync(h_bwtqs, c->d_qual, n, hipMemcpyDeviceToHost, c->stream));
+        if (h_lcp16) HIP_CHECK(hipMemcpyAsync(h_lcp16, c->d_lcp, 2 * n, hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+    });
+}
+
+extern "C" int bfq_fastq_run(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int keep_headers, uint8_t *h_out,
+                             uint64_t cap, uint64_t *out_len, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        if (st) memset(st, 0, sizeof *st);
+        DevText txt;
+        fastq_upload_and_reserve(c, h_fastq, len, txt);
+        c->zeroCounters();
+        u8 *d_fq = txt.p;
+        DevFastq fq;
+        bfq_fastq_parse(c, d_fq, len, &fq);
+        u8 *ob = c->alloc<u8>(fq.total + 64), *oq = c->alloc<u8>(fq.total + 64);
+        size_t m = c->mark();
+        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
+        steps234_device(c, fq.roff, ob, oq);
+        c->release(m);                                         // the formatted text may reuse the pipeline's space
+        u8 *d_out = nullptr;
+        u64 ol = bfq_fastq_format(c, ob, oq, fq.roff, fq.N, keep_headers ? 2 : 0, d_fq, len, &fq, &d_out);
+        if (out_len) *out_len = ol;
+        if (ol > cap) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
+        if (ol) HIP_CHECK(hipMemcpyAsync(h_out, d_out, ol, hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+        fill_stats(c, st);
+    });
+}
+
+extern "C" int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp,
+                                       int lcp_bytes, uint64_t n, const uint8_t *h_headers, uint64_t headers_len,
+                                       uint8_t *h_out, uint64_t cap, uint64_t *out_len, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        SmoothOut r;
+        smooth_invert_core(c, h_bwt, h_bwtqs, h_lcp, lcp_bytes, n, 3 * (n + 4096) + 2 * headers_len + (32u << 20), st, &r);
+        u8 *d_hdr = nullptr;
+        if (h_headers) {
+            d_hdr = c->alloc<u8>(headers_len + 64);
+            if (headers_len) HIP_CHECK(hipMemcpyAsync(d_hdr, h_headers, headers_len, hipMemcpyHostToDevice, c->stream));
+        }
+        u8 *d_out = nullptr;
+        u64 ol = bfq_fastq_format(c, r.ob, r.oq, r.roff, r.N, h_headers ? 1 : 0, d_hdr, headers_len, nullptr, &d_out);
+        if (out_len) *out_len = ol;
+        if (ol > cap) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
+        if (ol) HIP_CHECK(hipMemcpyAsync(h_out, d_out, ol, hipMemcpyDeviceToHost, c->stream));
         c->fetchCounters();
         c->profCollect();
         check_counters(c);

@@ -24,7 +24,7 @@ struct BfqError {
 enum BfqKernel {
     K_TEXT = 0, K_PACK, K_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_SEG_FLAGS, K_SEG_COMPACT,
     K_REFINE_WAVE, K_REFINE_BIG, K_EMIT, K_RANK_BUILD, K_RANK_FINAL, K_LCP_FLAGS, K_CLUSTER_COMPACT, K_CLUSTER,
-    K_INVERT_COUNT, K_INVERT, K_SYNTH, K_MISC, K_NUM
+    K_INVERT_COUNT, K_INVERT, K_SYNTH, K_FASTQ, K_MISC, K_NUM
 };
 extern const char *const BFQ_KERNEL_NAMES[K_NUM];
 
@@ -41,7 +41,8 @@ struct DevCounters {
     u64 tot[6];          // symbol totals of the eBWT: # A C G N T
     u64 mismatch;        // >0: rebuilt eBWT differs from the given one
     u64 nSegs;           // segments of >= 2 rows met by the refinement
-    u64 pad[10];
+    u64 errFastq;        // >0: a record whose quality line is not as long as its sequence
+    u64 pad[9];
 };
 
 // the tabulated rank queries: one u64 per eBWT row (layout: bfq_rank.h)
@@ -141,3 +142,9 @@ void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);
 void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals);
 
 void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, u64 *d_roff);
+
+// FASTQ text on the device (k_fastq.hip)
+struct DevFastq { u64 N, total; void *rec; u64 *roff; u8 *bases, *quals; u64 *lineEnd; };
+void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq);
+u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, int mode, const u8 *d_hdr,
+                     u64 hdrLen, const DevFastq *fq, u8 **d_out);

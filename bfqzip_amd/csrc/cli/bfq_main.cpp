@@ -118,46 +118,24 @@ int main(int argc, char **argv)
     printf("Number of reads: %llu\n", (unsigned long long)N);
     bfq_ctx *c = bfq_create(0, &P);
     if (!c) { fprintf(stderr, "%s: %s\n", TOOL, bfq_create_error()); return 1; }
-    std::vector<uint8_t> ob(n - N + 1), oq(n - N + 1);
-    std::vector<uint64_t> off(N + 1);
+    // the FASTQ text (header line verbatim from -H, else "@"; bases; "+"; qualities -- bfq_int.cpp:797-810)
+    // is laid out on the GPU and written with one fwrite
+    if (headers && !read_file(titles, hdr)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, titles.c_str()); return 1; }
+    uint64_t hdrBytes = 0;
+    if (headers) { hdrBytes = hdr.size(); }
+    uint64_t cap = bfq_fastq_out_bound(n - N, N, headers ? hdrBytes + 1 : 0) + 64, outLen = 0;
+    std::vector<uint8_t> outText(cap);
     bfq_stats st;
     int lb = (needLcp && n) ? (int)(lcp.size() / n) : 0;
-    int rc = bfq_smooth_invert(c, bwt.data(), qs.data(), needLcp ? lcp.data() : nullptr, lb, n, ob.data(), oq.data(),
-                               off.data(), &st);
+    int rc = bfq_smooth_invert_fastq(c, bwt.data(), qs.data(), needLcp ? lcp.data() : nullptr, lb, n,
+                                     headers ? hdr.data() : nullptr, hdr.size(), outText.data(), cap, &outLen, &st);
     if (rc) {
         fprintf(stderr, "%s: %s\n", TOOL, bfq_last_error(c));
         bfq_destroy(c);
         return 1;
     }
     bfq_destroy(c);
-
-    // bfq_int.cpp:797-810: header line (verbatim from -H, else "@"), bases, "+", qualities
-    std::vector<size_t> hs, he;
-    if (headers) {
-        if (!read_file(titles, hdr)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, titles.c_str()); return 1; }
-        size_t p = 0;
-        while (p < hdr.size()) {
-            const uint8_t *nl = (const uint8_t *)memchr(hdr.data() + p, '\n', hdr.size() - p);
-            size_t e = nl ? (size_t)(nl - hdr.data()) : hdr.size();
-            hs.push_back(p); he.push_back(e);
-            p = e + 1;
-        }
-    }
-    FILE *fo = fopen(output.c_str(), "wb");
-    if (!fo) { perror("invert"); return 1; }
-    std::vector<char> rec;
-    rec.reserve(1 << 20);
-    for (uint64_t i = 0; i < N; i++) {
-        uint64_t s = off[i], e = off[i + 1];
-        if (headers && i < hs.size()) { rec.insert(rec.end(), hdr.begin() + hs[i], hdr.begin() + he[i]); rec.push_back('\n'); }
-        else if (!headers) { rec.push_back('@'); rec.push_back('\n'); }
-        rec.insert(rec.end(), ob.begin() + s, ob.begin() + e); rec.push_back('\n');
-        rec.push_back('+'); rec.push_back('\n');
-        rec.insert(rec.end(), oq.begin() + s, oq.begin() + e); rec.push_back('\n');
-        if (rec.size() > (1 << 20) - 70000) { fwrite(rec.data(), 1, rec.size(), fo); rec.clear(); }
-    }
-    if (!rec.empty()) fwrite(rec.data(), 1, rec.size(), fo);
-    fclose(fo);
+    if (!write_file(output, outText.data(), outLen)) { perror("invert"); return 1; }
 
     // bfq_int.cpp:1004-1019
     double nb = (double)(n - N), nc = (double)st.num_clust;

@@ -30,20 +30,17 @@ int main(int argc, char **argv)
     if (in.empty()) { fprintf(stderr, "%s: no input FASTQ\n", tool); return 1; }
     if (out.empty()) out = in;
     if (lbytes != 1 && lbytes != 2 && lbytes != 4) { fprintf(stderr, "%s: --lbytes must be 1, 2 or 4\n", tool); return 1; }
-    std::vector<uint8_t> buf, bases, quals;
-    std::vector<uint64_t> off;
-    std::string err;
+    // the file's bytes go to the GPU as they are: records are indexed, split and sorted there
+    std::vector<uint8_t> buf;
     if (!read_file(in, buf)) { fprintf(stderr, "%s: cannot read %s\n", tool, in.c_str()); return 1; }
-    if (!parse_fastq(buf, bases, quals, off, err)) { fprintf(stderr, "%s: %s: %s\n", tool, in.c_str(), err.c_str()); return 1; }
-    buf.clear(); buf.shrink_to_fit();
-    uint64_t N = off.size() - 1, n = bases.size() + N;
     bfq_ctx *c = bfq_create(0, nullptr);
     if (!c) { fprintf(stderr, "%s: %s\n", tool, bfq_create_error()); return 1; }
-    std::vector<uint8_t> bwt(n), qs(n);
-    std::vector<uint16_t> lcp(wantLcp ? n : 0);
-    int rc = bfq_build_ebwt(c, bases.data(), quals.data(), off.data(), N, term, bwt.data(), qs.data(),
-                            wantLcp ? lcp.data() : nullptr);
-    if (rc) { fprintf(stderr, "%s: %s\n", tool, bfq_last_error(c)); bfq_destroy(c); return 1; }
+    uint64_t cap = buf.size() / 2 + 1, n = 0, N = 0;
+    std::vector<uint8_t> bwt(cap), qs(cap);
+    std::vector<uint16_t> lcp(wantLcp ? cap : 0);
+    int rc = bfq_fastq_build_ebwt(c, buf.data(), buf.size(), term, bwt.data(), qs.data(), wantLcp ? lcp.data() : nullptr, cap,
+                                  &n, &N);
+    if (rc) { fprintf(stderr, "%s: %s: %s\n", tool, in.c_str(), bfq_last_error(c)); bfq_destroy(c); return 1; }
     bfq_destroy(c);
     bool ok = write_file(out + ".bwt", bwt.data(), n) && write_file(out + ".bwt.qs", qs.data(), n);
     if (ok && wantLcp) {

@@ -1,0 +1,248 @@
+// k_fastq.hip -- FASTQ text <-> read arrays on the GPU.
+//
+// The reference's drivers pull the streams apart with `sed -n 1~4p / 2~4p / 4~4p`
+// (BFQzip.py:192-251) and bfq_int writes records with four fwrite()s per read
+// (bfq_int.cpp:797-810).  Here the 4-line records are indexed and gathered / written by
+// streaming kernels, so the front-ends hand whole files to the GPU:
+//   k_nl_count / k_nl_write : positions of all line ends (ordered compaction)
+//   k_fq_records            : per record: header span, sequence / quality start, length
+//                             (CR before LF stripped; len(DNA) != len(QS) is an error, checkFASTQ.py:18-32)
+//   k_fq_gather             : lines 2 and 4 -> bases / quals back to back (one wave per read)
+//   k_fq_format             : header line (verbatim, or "@"), bases, "+", quals (one wave per read)
+#include "bfq_internal.h"
+#include "bfq_device.h"
+
+#define NL_CHUNK 4096                                  // bytes per workgroup iteration (16 per thread)
+
+__device__ __forceinline__ u32 nl_mask16(const u8 *__restrict__ buf, u64 pos, u64 len)
+{
+    u32 m = 0;
+    if (pos + 16 <= len) {
+        uint4 v = *(const uint4 *)(buf + pos);         // buf is 16-byte aligned, pos a multiple of 16
+        u32 wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) m |= (((wds[k] >> (8 * b)) & 0xFFu) == 10u ? 1u : 0u) << (4 * k + b);
+    } else {
+        for (int k = 0; k < 16; k++)
+            if (pos + k < len && buf[pos + k] == 10) m |= 1u << k;
+    }
+    return m;
+}
+
+__global__ __launch_bounds__(256) void k_nl_count(const u8 *__restrict__ buf, u64 len, u32 *__restrict__ counts, u64 nchunks)
+{
+    __shared__ u32 sh[4];
+    for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        u32 c = __popc(nl_mask16(buf, ch * NL_CHUNK + (u64)threadIdx.x * 16, len));
+        u32 tot;
+        bfq_block_exscan32(c, sh, &tot);
+        if (threadIdx.x == 0) counts[ch] = tot;
+    }
+}
+__global__ __launch_bounds__(256) void k_nl_write(const u8 *__restrict__ buf, u64 len, const u64 *__restrict__ chunkBase,
+                                                  u64 *__restrict__ lineEnd, u64 nchunks)
+{
+    __shared__ u32 sh[4];
+    for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+        u64 pos = ch * NL_CHUNK + (u64)threadIdx.x * 16;
+        u32 m = nl_mask16(buf, pos, len);
+        u32 tot;
+        u32 ex = bfq_block_exscan32(__popc(m), sh, &tot);
+        u64 o = chunkBase[ch] + ex;
+        while (m) { int k = __builtin_ctz(m); lineEnd[o++] = pos + k; m &= m - 1; }
+    }
+}
+
+struct FqRec { u64 hdrStart, seqStart, qualStart; u32 hdrLen, len; };
+
+__global__ __launch_bounds__(256) void k_fq_records(const u8 *__restrict__ buf, const u64 *__restrict__ lineEnd, u64 N, FqRec *__restrict__ rec, u32 *__restrict__ lens,
+                                                    DevCounters *cnt)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        u64 e[4], s[4];
+        for (int k = 0; k < 4; k++) {
+            u64 li = 4 * i + k;
+            s[k] = li ? lineEnd[li - 1] + 1 : 0;
+            e[k] = lineEnd[li];
+            if (k && e[k] > s[k] && buf[e[k] - 1] == 13) e[k]--;    // CRLF (header lines are passed through verbatim)
+        }
+        FqRec r;
+        r.hdrStart = s[0]; r.hdrLen = (u32)(e[0] - s[0]);
+        r.seqStart = s[1]; r.qualStart = s[3];
+        u64 l = e[1] - s[1];
+        if (e[3] - s[3] != l) atomicAdd(&cnt->errFastq, 1ull);
+        if (l > BFQ_MAX_READ_LEN) { atomicAdd(&cnt->errTooLong, 1ull); l = 0; }
+        r.len = (u32)l;
+        rec[i] = r;
+        lens[i] = (u32)l;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fq_gather(const u8 *__restrict__ buf, const FqRec *__restrict__ rec,
+                                                   const u64 *__restrict__ roff, u64 N, u8 *__restrict__ bases,
+                                                   u8 *__restrict__ quals)
+{
+    u32 lane = bfq_lane();
+    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
+        FqRec r = rec[i];
+        u64 o = roff[i];
+        for (u32 k = lane; k < r.len; k += 64) {
+            bases[o + k] = buf[r.seqStart + k];
+            quals[o + k] = buf[r.qualStart + k];
+        }
+    }
+}
+
+// record i: header (hLen[i] bytes at hdr + hStart[i], or "@" when hdr == nullptr) \n bases \n + \n quals \n
+__global__ __launch_bounds__(256) void k_fq_hdr_from_lines(const u64 *__restrict__ hdrEnd, u64 N, u64 *__restrict__ hStart,
+                                                           u32 *__restrict__ hLen)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        u64 s0 = i ? hdrEnd[i - 1] + 1 : 0;
+        hStart[i] = s0; hLen[i] = (u32)(hdrEnd[i] - s0);
+    }
+}
+__global__ __launch_bounds__(256) void k_fq_hdr_from_recs(const FqRec *__restrict__ rec, u64 N, u64 *__restrict__ hStart,
+                                                          u32 *__restrict__ hLen)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        hStart[i] = rec[i].hdrStart; hLen[i] = rec[i].hdrLen;
+    }
+}
+__global__ __launch_bounds__(256) void k_fq_recsize(const u64 *__restrict__ roff, const u32 *__restrict__ hLen, u64 N,
+                                                    u32 *__restrict__ sizes)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
+        u64 L = roff[i + 1] - roff[i];
+        sizes[i] = (u32)((hLen ? hLen[i] : 1u) + 2 * L + 5);
+    }
+}
+__global__ __launch_bounds__(256) void k_fq_format(const u8 *__restrict__ bases, const u8 *__restrict__ quals,
+                                                   const u64 *__restrict__ roff, const u8 *__restrict__ hdr,
+                                                   const u64 *__restrict__ hStart, const u32 *__restrict__ hLen,
+                                                   const u64 *__restrict__ recOff, u64 N, u8 *__restrict__ out)
+{
+    u32 lane = bfq_lane();
+    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
+        u64 b = roff[i], L = roff[i + 1] - b, o = recOff[i];
+        u64 hs = hdr ? hStart[i] : 0, hl = hdr ? hLen[i] : 1;
+        for (u64 k = lane; k < hl; k += 64) out[o + k] = hdr ? hdr[hs + k] : (u8)'@';
+        o += hl;
+        if (lane == 0) { out[o] = 10; out[o + 1 + L] = 10; out[o + 2 + L] = (u8)'+'; out[o + 3 + L] = 10; out[o + 4 + 2 * L] = 10; }
+        for (u64 k = lane; k < L; k += 64) {
+            out[o + 1 + k] = bases[b + k];
+            out[o + 4 + L + k] = quals[b + k];
+        }
+    }
+}
+
+// positions of the line ends of a text resident on the device; a last line without newline gets a
+// virtual end at `len`.  *nlines = number of lines.
+static u64 *line_index(bfq_ctx *c, const u8 *d_buf, u64 len, u64 *nlines)
+{
+    u64 nchunks = ceil_div(len ? len : 1, NL_CHUNK);
+    u32 *counts = c->alloc<u32>(nchunks);
+    u64 *bases = c->alloc<u64>(nchunks);
+    u64 *d_total = c->alloc<u64>(1);
+    KLAUNCH(c, K_FASTQ, (double)len, k_nl_count, bfq_grid(nchunks, 1), 256, d_buf, len, counts, nchunks);
+    bfq_exscan_u32(c, counts, bases, nchunks, d_total);
+    u64 nl = 0;
+    HIP_CHECK(hipMemcpyAsync(&nl, d_total, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    u8 last = 10;
+    if (len) HIP_CHECK(hipMemcpyAsync(&last, d_buf + len - 1, 1, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    u64 *lineEnd = c->alloc<u64>(nl + 2);
+    if (nl) KLAUNCH(c, K_FASTQ, (double)len + 8.0 * (double)nl, k_nl_write, bfq_grid(nchunks, 1), 256, d_buf, len,
+                    (const u64 *)bases, lineEnd, nchunks);
+    if (len && last != 10) {
+        HIP_CHECK(hipMemcpyAsync(lineEnd + nl, &len, sizeof(u64), hipMemcpyHostToDevice, c->stream));
+        c->sync();                                              // &len is a stack variable
+        nl++;
+    }
+    *nlines = nl;
+    return lineEnd;
+}
+
+u64 bfq_fastq_count_lines(bfq_ctx *c, const u8 *d_buf, u64 len)
+{
+    size_t m = c->mark();
+    u64 nchunks = ceil_div(len ? len : 1, NL_CHUNK);
+    u32 *counts = c->alloc<u32>(nchunks);
+    u64 *bases = c->alloc<u64>(nchunks);
+    u64 *d_total = c->alloc<u64>(1);
+    KLAUNCH(c, K_FASTQ, (double)len, k_nl_count, bfq_grid(nchunks, 1), 256, d_buf, len, counts, nchunks);
+    bfq_exscan_u32(c, counts, bases, nchunks, d_total);
+    u64 nl = 0;
+    HIP_CHECK(hipMemcpyAsync(&nl, d_total, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->release(m);
+    return nl + 1;
+}
+
+void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq)
+{
+    u64 nlines = 0;
+    u64 *lineEnd = line_index(c, d_fastq, len, &nlines);
+    if (nlines % 4) throw BfqError{BFQ_E_ARG, "FASTQ: number of lines is not a multiple of 4"};
+    u64 N = nlines / 4;
+    fq->N = N;
+    fq->rec = c->alloc<FqRec>(N + 1);
+    fq->roff = c->alloc<u64>(N + 2);
+    u32 *lens = c->alloc<u32>(N + 1);
+    if (N)
+        KLAUNCH(c, K_FASTQ, 40.0 * (double)N, k_fq_records, bfq_grid(N, 256), 256, d_fastq, (const u64 *)lineEnd, N,
+                (FqRec *)fq->rec, lens, c->d_cnt);
+    bfq_exscan_u32(c, lens, fq->roff, N, fq->roff + N);
+    HIP_CHECK(hipMemcpyAsync(&fq->total, fq->roff + N, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    c->fetchCounters();
+    if (c->h_cnt.errFastq) throw BfqError{BFQ_E_ARG, "FASTQ: len(DNA) != len(QS) in a record"};
+    if (c->h_cnt.errTooLong) throw BfqError{BFQ_E_TOO_LONG, "read longer than BFQ_MAX_READ_LEN"};
+    fq->bases = c->alloc<u8>(fq->total + 64);
+    fq->quals = c->alloc<u8>(fq->total + 64);
+    if (N) {
+        u64 waves = N < (1u << 18) ? N : (1u << 18);
+        KLAUNCH(c, K_FASTQ, 4.0 * (double)fq->total, k_fq_gather, ceil_div(waves, 4), 256, d_fastq, (const FqRec *)fq->rec,
+                (const u64 *)fq->roff, N, fq->bases, fq->quals);
+    }
+    fq->lineEnd = lineEnd;
+}
+
+// Headers: mode 0 = "@"; 1 = d_hdr is a text of header lines (bfq_int -H); 2 = d_hdr is the FASTQ
+// text parsed into `fq` (its records' own header lines).  Returns the formatted length, text in *d_out (arena).
+u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, int mode, const u8 *d_hdr,
+                     u64 hdrLen, const DevFastq *fq, u8 **d_out)
+{
+    u64 *hStart = nullptr;
+    u32 *hLen = nullptr;
+    if (mode) {
+        hStart = c->alloc<u64>(N + 1);
+        hLen = c->alloc<u32>(N + 1);
+        if (mode == 1) {
+            u64 nl = 0;
+            const u64 *hdrEnd = line_index(c, d_hdr, hdrLen, &nl);
+            if (nl < N) throw BfqError{BFQ_E_ARG, "header file has fewer lines than there are reads"};
+            if (N) KLAUNCH(c, K_FASTQ, 20.0 * (double)N, k_fq_hdr_from_lines, bfq_grid(N, 256), 256, hdrEnd, N, hStart, hLen);
+        } else if (N) {
+            KLAUNCH(c, K_FASTQ, 44.0 * (double)N, k_fq_hdr_from_recs, bfq_grid(N, 256), 256, (const FqRec *)fq->rec, N, hStart, hLen);
+        }
+    }
+    u32 *sizes = c->alloc<u32>(N + 1);
+    u64 *recOff = c->alloc<u64>(N + 2);
+    if (N) KLAUNCH(c, K_FASTQ, 12.0 * (double)N, k_fq_recsize, bfq_grid(N, 256), 256, d_roff, (const u32 *)hLen, N, sizes);
+    bfq_exscan_u32(c, sizes, recOff, N, recOff + N);
+    u64 outLen = 0;
+    HIP_CHECK(hipMemcpyAsync(&outLen, recOff + N, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    u8 *out = c->alloc<u8>(outLen + 64);
+    if (N) {
+        u64 waves = N < (1u << 18) ? N : (1u << 18);
+        KLAUNCH(c, K_FASTQ, 2.0 * (double)outLen, k_fq_format, ceil_div(waves, 4), 256, d_bases, d_quals, d_roff,
+                mode ? d_hdr : (const u8 *)nullptr, (const u64 *)hStart, (const u32 *)hLen, (const u64 *)recOff, N, out);
+    }
+    *d_out = out;
+    return outLen;
+}

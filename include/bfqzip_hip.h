@@ -100,6 +100,27 @@ int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_qu
                          const uint64_t *d_read_off, uint64_t N, uint64_t total,
                          uint8_t *d_out_bases, uint8_t *d_out_quals, bfq_stats *st);
 
+/* ---- FASTQ text in / out, parsed and formatted on the GPU (host buffers).
+ * Records are 4 lines; CR before LF is dropped from lines 2 and 4; a record whose quality line is
+ * not as long as its sequence is an error (checkFASTQ.py:18-32).
+ *   bfq_fastq_build_ebwt   : gsufsort / eGap on the file's bytes; outputs hold cap_rows entries
+ *                            (len/2 + 1 is always enough); *n_rows / *n_reads receive the sizes.
+ *   bfq_fastq_run          : the whole path, text to text; keep_headers != 0 passes every record's
+ *                            header line through (BFQzip.py --headers), else "@" (bfq_int.cpp:758,805).
+ *   bfq_smooth_invert_fastq: bfq_int / bfq_ext writing the FASTQ text itself; h_headers = the -H file
+ *                            (one line per read) or NULL.
+ * Output size: bfq_fastq_out_bound(total bases, reads, header bytes without newlines or 0). */
+uint64_t bfq_fastq_out_bound(uint64_t total_bases, uint64_t n_reads, uint64_t header_bytes);
+int bfq_fastq_build_ebwt(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int term_out,
+                         uint8_t *h_bwt, uint8_t *h_bwtqs, uint16_t *h_lcp16, uint64_t cap_rows,
+                         uint64_t *n_rows, uint64_t *n_reads);
+int bfq_fastq_run(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int keep_headers,
+                  uint8_t *h_out, uint64_t cap, uint64_t *out_len, bfq_stats *st);
+int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs,
+                            const void *h_lcp, int lcp_bytes, uint64_t n,
+                            const uint8_t *h_headers, uint64_t headers_len,
+                            uint8_t *h_out, uint64_t cap, uint64_t *out_len, bfq_stats *st);
+
 /* Device-resident eBWT of the last bfq_run_reads*() / bfq_build_ebwt() call
  * (valid until the next call on the context): copies to host. Any may be NULL.
  * h_bwtqs receives the permuted qualities as built (before smoothing). */
