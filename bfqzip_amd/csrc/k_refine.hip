@@ -154,11 +154,9 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                 curHeads = __ballot(!act || (int)lane == sublo);
                 u32 depth = BFQ_KEY_SYMS;
                 u32 round = 0;
-                u64 Wn = act ? wo_key(text3, v, 0) : 0ull;
                 while (unres) {
                     const bool un = (unres >> lane) & 1ull;
-                    u64 W = Wn;
-                    Wn = (un && !bfq_key_has_term(W)) ? wo_key(text3, v, round + 1) : 0ull;
+                    u64 W = un ? wo_key(text3, v, round) : 0ull;
                     // longest open sub-segment = longest run of non-head lanes + 1 (scalar bit trick on the head mask)
                     u32 maxsz = 1;
                     for (u64 run = ~curHeads; run; run &= run >> 1) maxsz++;
@@ -179,7 +177,6 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                     int np = un ? sublo + c : (int)lane;
                     v = bfq_permute64(v, np);
                     W = bfq_permute64(W, np);
-                    Wn = bfq_permute64(Wn, np);
                     u64 Wprev = bfq_from_prev_lane(W);
                     bool newhead = un && ((int)lane == sublo || W != Wprev || bfq_key_has_term(W));
                     if (un && (int)lane != sublo && newhead) mylcp = depth + (u32)bfq_key_lcp(Wprev, W);
