@@ -7,26 +7,52 @@
 #include "bfq_internal.h"
 #include "bfq_device.h"
 
-// one wave per read: symbol codes + qualities into terminated text order
+// 16 lanes per read, 8 bytes per lane and step (unaligned 8-byte loads/stores are fine on gfx950):
+// symbol codes + qualities into terminated text order
+__device__ __forceinline__ u64 codes8(u64 x, bool *bad)      // 8 ASCII bases -> 8 codes
+{
+    // (c >> 1) & 7 separates A0 C1 T2 G3 N7; nibble LUTs give the code and the letter to verify against
+    u64 out = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        u32 c = (u32)(x >> (8 * k)) & 0xFFu;
+        u32 h = (c >> 1) & 7u;
+        u32 code = (0x40003521u >> (4 * h)) & 0xFu;                       // h: 0 1 2 3 . . . 7 -> 1 2 5 3 . . . 4
+        u32 want = (u32)((0x4E00000047544341ull >> (8 * h)) & 0xFFu);     // 'A' 'C' 'T' 'G' . . . 'N'
+        if (c != want || code == 0) { *bad = true; code = 4; }
+        out |= (u64)code << (8 * k);
+    }
+    return out;
+}
+
 __global__ __launch_bounds__(256) void k_text_from_reads(const u8 *__restrict__ bases, const u8 *__restrict__ quals,
                                                          const u64 *__restrict__ roff, u64 N, u8 *__restrict__ T8,
                                                          u8 *__restrict__ Q8, DevCounters *cnt)
 {
-    u32 lane = bfq_lane();
-    u64 wave = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    const u32 sub = threadIdx.x & 15u;
+    u64 grp = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const u64 ngrp = ((u64)gridDim.x * blockDim.x) >> 4;
     bool bad = false, tooLong = false;
-    for (u64 i = wave; i < N; i += nwaves) {
+    for (u64 i = grp; i < N; i += ngrp) {
         u64 b = roff[i], e = roff[i + 1];
         u64 t0 = b + i, len = e - b;
         if (len > BFQ_MAX_READ_LEN) tooLong = true;
-        for (u64 k = lane; k < len; k += 64) {
-            u32 code = bfq_base_code(bases[b + k]);
-            if (code == BFQ_CODE_INVALID) { bad = true; code = 4; }
-            T8[t0 + k] = (u8)code;
-            Q8[t0 + k] = quals[b + k];
+        for (u64 k = (u64)sub * 8; k < len; k += 128) {
+            if (k + 8 <= len) {
+                u64 xb = *(const u64 *)(bases + b + k);
+                u64 xq = *(const u64 *)(quals + b + k);
+                *(u64 *)(T8 + t0 + k) = codes8(xb, &bad);
+                *(u64 *)(Q8 + t0 + k) = xq;
+            } else {
+                for (u64 j = k; j < len; j++) {
+                    u32 code = bfq_base_code(bases[b + j]);
+                    if (code == BFQ_CODE_INVALID) { bad = true; code = 4; }
+                    T8[t0 + j] = (u8)code;
+                    Q8[t0 + j] = quals[b + j];
+                }
+            }
         }
-        if (lane == 0) { T8[t0 + len] = 0; Q8[t0 + len] = (u8)'#'; }
+        if (sub == 0) { T8[t0 + len] = 0; Q8[t0 + len] = (u8)'#'; }
     }
     if (bad) atomicAdd(&cnt->errSymbol, 1ull);
     if (tooLong) atomicAdd(&cnt->errTooLong, 1ull);
@@ -69,8 +95,7 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
                     u8 *Q8, u64 *text3, u64 nwords)
 {
     if (N) {
-        u64 waves = N < (1u << 18) ? N : (1u << 18);
-        u64 blocks = ceil_div(waves, 4);
+        u64 blocks = bfq_grid(N, 16);                      // 16 lanes per read
         KLAUNCH(c, K_TEXT, 4.0 * (double)(n - N), k_text_from_reads, blocks, 256, d_bases, d_quals, d_roff, N, T8, Q8,
                 c->d_cnt);
     }
