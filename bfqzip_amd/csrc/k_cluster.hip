@@ -64,12 +64,17 @@ __device__ __forceinline__ void set_mod(const ClusterArgs &a, u64 j, u8 sym)
 __device__ __forceinline__ void mod_smooth(const ClusterArgs &a, u64 start, u64 end, u8 newSymb, int newqs, u32 lowQS, ClStat &st)
 {
     const u8 TERM = (u8)a.term;
-    for (u64 j = start; j <= end; j++) {
-        u8 b = a.bwt[j];
-        if (b == TERM) continue;
-        if (b != newSymb && !((lowQS >> ord5(b)) & 1u)) { set_mod(a, j, newSymb); st.modb++; }
-        else if (b == newSymb) { set_qual(a, j, newqs); st.qs++; }
-        else if (newqs < (int)(signed char)a.qual[j]) { set_qual(a, j, newqs); st.qs++; }
+    for (u64 j0 = start; j0 <= end; j0 += 8) {                                 // 8 rows per (unaligned) 8-byte load
+        u64 xb = *(const u64 *)(a.bwt + j0), xq = *(const u64 *)(a.qual + j0);
+        u32 cnt = (end - j0 + 1 < 8) ? (u32)(end - j0 + 1) : 8u;
+        for (u32 k = 0; k < cnt; k++) {
+            u64 j = j0 + k;
+            u8 b = (u8)(xb >> (8 * k));
+            if (b == TERM) continue;
+            if (b != newSymb && !((lowQS >> ord5(b)) & 1u)) { set_mod(a, j, newSymb); st.modb++; }
+            else if (b == newSymb) { set_qual(a, j, newqs); st.qs++; }
+            else if (newqs < (int)(signed char)(u8)(xq >> (8 * k))) { set_qual(a, j, newqs); st.qs++; }
+        }
     }
 }
 
@@ -81,12 +86,16 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
     u32 freqs[5] = {0, 0, 0, 0, 0};
     u32 lowQS = 0;
     u64 base_num = 0;
-    for (u64 j = start; j <= end; j++) {                                       // :437-449
-        u8 b = a.bwt[j];
-        if (b != TERM) {
-            int o = ord5(b);
-            freqs[o]++; base_num++;
-            if ((int)(signed char)a.qual[j] >= a.t + 33) lowQS |= 1u << o;
+    for (u64 j0 = start; j0 <= end; j0 += 8) {                                 // :437-449, 8 rows per 8-byte load
+        u64 xb = *(const u64 *)(a.bwt + j0), xq = *(const u64 *)(a.qual + j0);
+        u32 cnt = (end - j0 + 1 < 8) ? (u32)(end - j0 + 1) : 8u;
+        for (u32 k = 0; k < cnt; k++) {
+            u8 b = (u8)(xb >> (8 * k));
+            if (b != TERM) {
+                int o = ord5(b);
+                freqs[o]++; base_num++;
+                if ((int)(signed char)(u8)(xq >> (8 * k)) >= a.t + 33) lowQS |= 1u << o;
+            }
         }
     }
     st.clust++;
@@ -208,7 +217,14 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
             u32 idx = t - (ww == 0 ? 0u : (ww == 1 ? n0 : (ww == 2 ? n0 + n1 : n0 + n1 + n2)));
             u64 r = ch * CL_CHUNK + starts[ww][idx];
             u64 e = r;
-            while (e + 1 < a.n && a.in[e + 1]) e++;
+            for (;;) {                                              // in[] is padded: 8 flags per 8-byte load
+                u64 x = *(const u64 *)(a.in + e + 1);
+                u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;   // first zero byte
+                u32 run = z ? (u32)(__builtin_ctzll(z) >> 3) : 8u;
+                if (e + run >= a.n) run = (u32)(a.n - 1 - e);
+                e += run;
+                if (run < 8 || e + 1 >= a.n) break;
+            }
             process_cluster_body(a, r - 1, e, st);
         }
         __syncthreads();
