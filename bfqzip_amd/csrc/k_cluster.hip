@@ -18,14 +18,33 @@
 #include "bfq_device.h"
 #include "bfq_rank.h"
 
+// 8 rows per thread: ten LCP values in (two unaligned 8-byte loads + the two neighbours), eight flags out
 __global__ __launch_bounds__(256) void k_lcp_flags(const u16 *__restrict__ lcp, u64 n, int K, u8 *__restrict__ in)
 {
-    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
-        int l = (int)lcp[r];
-        bool thr = (r >= 1) && (l >= K);
-        bool mn = false;
-        if (r >= 1 && r + 2 <= n) mn = ((int)lcp[r - 1] > l) && ((int)lcp[r + 1] >= l);
-        in[r] = (thr && !mn) ? 1 : 0;
+    const u64 ngroups = (n + 7) / 8;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (u64)gridDim.x * blockDim.x) {
+        u64 r0 = g * 8;
+        int l[10];                                   // l[k] = LCP[r0 - 1 + k]
+        if (r0 >= 1 && r0 + 9 <= n) {
+            u64 a = *(const u64 *)(lcp + r0 - 1), b = *(const u64 *)(lcp + r0 + 3);
+            u32 c = *(const u32 *)(lcp + r0 + 7);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { l[k] = (int)((a >> (16 * k)) & 0xFFFF); l[4 + k] = (int)((b >> (16 * k)) & 0xFFFF); }
+            l[8] = (int)(c & 0xFFFF); l[9] = (int)(c >> 16);
+        } else {
+#pragma unroll
+            for (int k = 0; k < 10; k++) { u64 r = r0 + k; l[k] = (r >= 1 && r - 1 < n) ? (int)lcp[r - 1] : 0; }
+        }
+        u64 out = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            u64 r = r0 + k;
+            bool thr = (r >= 1) && (l[k + 1] >= K);
+            bool mn = (r >= 1 && r + 2 <= n) && (l[k] > l[k + 1]) && (l[k + 2] >= l[k + 1]);
+            out |= (u64)((thr && !mn) ? 1 : 0) << (8 * k);
+        }
+        if (r0 + 8 <= n) *(u64 *)(in + r0) = out;
+        else for (u64 r = r0; r < n; r++) in[r] = (u8)(out >> (8 * (r - r0)));
     }
 }
 
@@ -244,7 +263,7 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
 {
     if (!n) return;
-    KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, bfq_grid(n, 256), 256, lcp, n, K, in);
+    KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, bfq_grid((n + 7) / 8, 256), 256, lcp, n, K, in);
 }
 
 void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n)
