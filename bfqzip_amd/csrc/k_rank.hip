@@ -12,65 +12,89 @@
 #include "bfq_device.h"
 #include "bfq_rank.h"
 
-__device__ __forceinline__ u32 row_code(const u8 *__restrict__ bwt, u64 r, u64 n, u32 term, DevCounters *cnt)
+// One wavefront per group of 256 rows, 4 consecutive rows per lane (one 4-byte load of the eBWT and
+// one of the qualities).  Per-lane symbol counts travel packed in a u64 (6 fields of 10 bits).
+__device__ __forceinline__ u32 byte_code(u32 ch, u32 term, bool *bad)
 {
-    if (r >= n) return 7u;                          // rows past the end match no symbol
-    u8 ch = bwt[r];
-    u32 code = (ch == (u8)term) ? 0u : bfq_base_code(ch);
-    if (code == BFQ_CODE_INVALID) { if (cnt) atomicAdd(&cnt->errSymbol, 1ull); code = 4; }
+    u32 code = (ch == term) ? 0u : bfq_base_code((u8)ch);
+    if (code == BFQ_CODE_INVALID) { *bad = true; code = 4; }
     return code;
+}
+// codes of rows r0..r0+3 (7 = past the end) from 4 eBWT bytes
+__device__ __forceinline__ void codes4(const u8 *__restrict__ bwt, u64 r0, u64 n, u32 term, u32 *code, bool *bad)
+{
+    u32 x = 0;
+    if (r0 + 4 <= n) x = *(const u32 *)(bwt + r0);
+    else for (u64 k = 0; r0 + k < n; k++) x |= (u32)bwt[r0 + k] << (8 * k);
+#pragma unroll
+    for (int k = 0; k < 4; k++) code[k] = (r0 + k < n) ? byte_code((x >> (8 * k)) & 0xFFu, term, bad) : 7u;
+}
+__device__ __forceinline__ u64 packed_counts(const u32 *code)
+{
+    u64 p = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (code[k] < 6) p += 1ull << (10 * code[k]);
+    return p;
 }
 
 __global__ __launch_bounds__(256) void k_lf_count(const u8 *__restrict__ bwt, u64 n, u32 term, u32 *__restrict__ gcnt,
                                                   u64 ngroups, DevCounters *cnt)
 {
-    __shared__ u32 wc[4][6];
-    const u32 lane = bfq_lane(), w = threadIdx.x >> 6;
-    for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        u32 code = row_code(bwt, g * 256 + threadIdx.x, n, term, cnt);
-        u64 b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u);
-        if (lane < 6) {
-            u64 m = ((lane & 1u) ? b0 : ~b0) & ((lane & 2u) ? b1 : ~b1) & ((lane & 4u) ? b2 : ~b2);
-            wc[w][lane] = (u32)__popcll(m);
-        }
-        __syncthreads();
-        if (threadIdx.x < 6) gcnt[(u64)threadIdx.x * ngroups + g] = wc[0][threadIdx.x] + wc[1][threadIdx.x] + wc[2][threadIdx.x] + wc[3][threadIdx.x];
-        __syncthreads();
+    const u32 lane = bfq_lane();
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    bool bad = false;
+    for (u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < ngroups; g += nwaves) {
+        u32 code[4];
+        codes4(bwt, g * 256 + (u64)lane * 4, n, term, code, &bad);
+        u64 p = packed_counts(code);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) p += bfq_bpermute64(p, (int)(lane ^ d));      // wave total in every lane
+        if (lane < 6) gcnt[(u64)lane * ngroups + g] = (u32)(p >> (10 * lane)) & 0x3FFu;
     }
+    if (bad) atomicAdd(&cnt->errSymbol, 1ull);
 }
 
 __global__ __launch_bounds__(256) void k_lf_build(const u8 *__restrict__ bwt, const u8 *__restrict__ qs, u64 n, u32 term,
                                                   const u64 *__restrict__ scanned, u64 ngroups, const DevCounters *cnt,
                                                   u64 *__restrict__ lfq)
 {
-    __shared__ u32 wc[4][6];
-    __shared__ u64 F[6];
-    const u32 lane = bfq_lane(), w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {                         // F array in order # A C G N T (dna_bwt_n.hpp:46-61)
+    const u32 lane = bfq_lane();
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    u64 F[6];                                       // F array in order # A C G N T (dna_bwt_n.hpp:46-61)
+    {
         u64 acc = 0;
+#pragma unroll
         for (int s = 0; s < 6; s++) { F[s] = acc; acc += cnt->tot[s]; }
     }
-    const u64 ltmask = bfq_lanemask_lt();
-    for (u64 g = blockIdx.x; g < ngroups; g += gridDim.x) {
-        u64 r = g * 256 + threadIdx.x;
-        u32 code = row_code(bwt, r, n, term, nullptr);
-        u64 b0 = __ballot(code & 1u), b1 = __ballot(code & 2u), b2 = __ballot(code & 4u);
-        u64 peers = ((code & 1u) ? b0 : ~b0) & ((code & 2u) ? b1 : ~b1) & ((code & 4u) ? b2 : ~b2);
-        if (lane < 6) {
-            u64 m = ((lane & 1u) ? b0 : ~b0) & ((lane & 2u) ? b1 : ~b1) & ((lane & 4u) ? b2 : ~b2);
-            wc[w][lane] = (u32)__popcll(m);
-        }
-        __syncthreads();                            // also orders the F[] initialisation
-        if (r < n) {
+    bool bad = false;
+    for (u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < ngroups; g += nwaves) {
+        const u64 r0 = g * 256 + (u64)lane * 4;
+        u32 code[4];
+        codes4(bwt, r0, n, term, code, &bad);
+        u32 q4 = 0;
+        if (r0 + 4 <= n) q4 = *(const u32 *)(qs + r0);
+        else for (u64 k = 0; r0 + k < n; k++) q4 |= (u32)qs[r0 + k] << (8 * k);
+        u64 p = packed_counts(code);
+        u64 ex = bfq_wave_incscan64(p) - p;         // packed counts of the rows before mine in the group
+        u64 outv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 c = code[k];
             u64 x = 0;
-            if (code >= 1 && code <= 5) {
-                u32 before = (u32)__popcll(peers & ltmask);
-                for (u32 k = 0; k < w; k++) before += wc[k][code];
-                x = F[code] + scanned[(u64)code * ngroups + g] + before;
+            if (c >= 1 && c <= 5) {
+                u32 before = (u32)(ex >> (10 * c)) & 0x3FFu;
+                x = (c == 1 ? F[1] : c == 2 ? F[2] : c == 3 ? F[3] : c == 4 ? F[4] : F[5]) + scanned[(u64)c * ngroups + g] + before;
             }
-            lfq[r] = x | ((u64)code << 40) | ((u64)qs[r] << 48);
+            if (c < 6) ex += 1ull << (10 * c);
+            outv[k] = x | ((u64)(c & 7u) << 40) | ((u64)((q4 >> (8 * k)) & 0xFFu) << 48);
         }
-        __syncthreads();
+        if (r0 + 4 <= n) {
+            *(ulonglong2 *)(lfq + r0) = make_ulonglong2(outv[0], outv[1]);
+            *(ulonglong2 *)(lfq + r0 + 2) = make_ulonglong2(outv[2], outv[3]);
+        } else {
+            for (u64 k = 0; r0 + k < n; k++) lfq[r0 + k] = outv[k];
+        }
     }
 }
 
@@ -82,9 +106,9 @@ RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int ter
     size_t m = c->mark();
     u32 *gcnt = c->alloc<u32>(6 * ngroups);
     u64 *scanned = c->alloc<u64>(6 * ngroups);
-    KLAUNCH(c, K_RANK_BUILD, (double)n, k_lf_count, bfq_grid(ngroups, 1), 256, bwt, n, (u32)(term & 0xFF), gcnt, ngroups, c->d_cnt);
+    KLAUNCH(c, K_RANK_BUILD, (double)n, k_lf_count, bfq_grid(ngroups, 4), 256, bwt, n, (u32)(term & 0xFF), gcnt, ngroups, c->d_cnt);
     for (int s = 0; s < 6; s++) bfq_exscan_u32(c, gcnt + (u64)s * ngroups, scanned + (u64)s * ngroups, ngroups, &c->d_cnt->tot[s]);
-    KLAUNCH(c, K_RANK_FINAL, 10.0 * (double)n, k_lf_build, bfq_grid(ngroups, 1), 256, bwt, qs, n, (u32)(term & 0xFF),
+    KLAUNCH(c, K_RANK_FINAL, 10.0 * (double)n, k_lf_build, bfq_grid(ngroups, 4), 256, bwt, qs, n, (u32)(term & 0xFF),
             (const u64 *)scanned, ngroups, (const DevCounters *)c->d_cnt, lfq);
     c->release(m);
     R.lfq = lfq; R.n = n;
