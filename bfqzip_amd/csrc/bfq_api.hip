@@ -37,7 +37,7 @@ void bfq_ctx::reserve(size_t bytes)
         wsCap = bytes;
     }
     wsTop = 0;
-    d_bwt = d_qual = nullptr; d_lcp = nullptr; n = N = 0;
+    d_bwt = d_qual = nullptr; d_lcp = nullptr; d_gcnt = nullptr; n = N = 0;
 }
 void *bfq_ctx::allocBytes(size_t bytes)
 {
@@ -237,7 +237,7 @@ static size_t ws_need(u64 n, u64 N, u64 extra)
 {
     u64 nb = n / 32768 + 2;
     size_t need = 0;
-    need += 4 * (n + 256) + 1024;                       // bwt, qual, lcp16
+    need += 4 * (n + 256) + 24 * (n / 256 + 2) + 4096;  // bwt, qual, lcp16, symbol counts per group
     need += 8 * (n / 21 + 8);                           // packed text
     need += 6 * 4 * (n + 256);                          // sort records, ping-pong (2 x 12 B/row)
     need += 256 * nb * 12 + (nb + 4096) * 64;           // radix histograms + scan partials
@@ -256,6 +256,8 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     c->d_bwt = c->alloc<u8>(n + 64);
     c->d_qual = c->alloc<u8>(n + 64);
     c->d_lcp = c->alloc<u16>(n + 64);
+    c->d_gcnt = c->alloc<u32>(6 * (n / 256 + 1));
+    c->gcntTerm = termOut & 0xFF;
     if (!n) return;
     size_t m0 = c->mark();
     u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
@@ -270,7 +272,7 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     bfq_radix_sort(c, A, B, n);
     c->release(mB);                                     // the big-segment list reuses the B buffers
     bfq_refine(c, A, text3, n, c->d_lcp, st);
-    bfq_emit_bwt(c, A, n, termOut, c->d_bwt, c->d_qual);
+    bfq_emit_bwt(c, A, n, termOut, c->d_bwt, c->d_qual, c->d_gcnt);
     c->release(m0);
 }
 
@@ -280,7 +282,9 @@ static void steps234_device(bfq_ctx *c, const u64 *d_roff, u8 *d_out_bases, u8 *
     u64 n = c->n, N = c->N;
     if (!n) return;
     if ((((uintptr_t)d_out_bases) | ((uintptr_t)d_out_quals)) & 7) throw BfqError{BFQ_E_ARG, "output buffers must be 8-byte aligned"};
-    RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term);
+    // the symbol counts of step 1's emission are reused when this eBWT is the one it just wrote
+    const u32 *gc = (c->d_gcnt && c->gcntTerm == (c->P.term & 0xFF)) ? c->d_gcnt : nullptr;
+    RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term, gc);
     u8 *in = c->alloc<u8>(n + 64);
     bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
     bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n);

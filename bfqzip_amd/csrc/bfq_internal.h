@@ -74,6 +74,8 @@ struct bfq_ctx {
 
     // last eBWT (device, inside ws)
     u8 *d_bwt = nullptr; u8 *d_qual = nullptr; u16 *d_lcp = nullptr;
+    u32 *d_gcnt = nullptr;          // symbol counts per 256-row group, written by k_emit_bwt
+    int gcntTerm = -1;              // terminator byte those counts were taken with
     u64 n = 0, N = 0;
 
     // profiling
@@ -128,13 +130,13 @@ void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u6
 void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n);
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
 void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
-void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs);
+void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs, u32 *gcnt);   // gcnt: [6][n/256+1] symbol counts
 // whole step 1 on device-resident reads; leaves c->d_bwt/d_qual/d_lcp
 void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,
                       int termOut, bfq_stats *st);
 
 // steps 2-4 pieces
-RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int term);
+RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int term, const u32 *gcnt = nullptr);
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in);
 void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n);
 // LF walks: lengths only, then emission at given offsets

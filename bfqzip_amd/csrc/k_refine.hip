@@ -264,13 +264,33 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
 }
 
 // eBWT byte and permuted quality of every row, from the sort payload
-__global__ __launch_bounds__(256) void k_emit_bwt(SortRec rec, u64 n, u32 termOut, u8 *__restrict__ bwt, u8 *__restrict__ qs)
+// One wavefront per group of 256 rows, 4 rows per lane (32 contiguous bytes of payload in, 4 + 4 bytes out);
+// the group's symbol counts (what k_lf_count would recount from the eBWT bytes) come out on the way.
+__global__ __launch_bounds__(256) void k_emit_bwt(SortRec rec, u64 n, u32 termOut, u8 *__restrict__ bwt, u8 *__restrict__ qs,
+                                                  u32 *__restrict__ gcnt, u64 ngroups)
 {
-    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
-        u64 v = rec_pay(rec, r);
-        u32 code = bfq_val_code(v);
-        bwt[r] = code ? bfq_code_sym(code) : (u8)termOut;
-        qs[r] = (u8)bfq_val_qual(v);
+    const u32 lane = bfq_lane();
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < ngroups; g += nwaves) {
+        const u64 r0 = g * 256 + (u64)lane * 4;
+        u32 b4 = 0, q4 = 0;
+        u64 p = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (r0 + k < n) {
+                u64 x = rec.w12[r0 + k];
+                u64 v = bfq_rec_pay((u32)x, (u32)(x >> 32));
+                u32 code = bfq_val_code(v);
+                b4 |= (u32)(code ? bfq_code_sym(code) : (u8)termOut) << (8 * k);
+                q4 |= bfq_val_qual(v) << (8 * k);
+                p += 1ull << (10 * code);
+            }
+        }
+        if (r0 + 4 <= n) { *(u32 *)(bwt + r0) = b4; *(u32 *)(qs + r0) = q4; }
+        else for (u64 k = 0; r0 + k < n; k++) { bwt[r0 + k] = (u8)(b4 >> (8 * k)); qs[r0 + k] = (u8)(q4 >> (8 * k)); }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) p += bfq_bpermute64(p, (int)(lane ^ d));
+        if (lane < 6) gcnt[(u64)lane * ngroups + g] = (u32)(p >> (10 * lane)) & 0x3FFu;
     }
 }
 
@@ -291,8 +311,9 @@ void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_
     c->release(m);
 }
 
-void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs)
+void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs, u32 *gcnt)
 {
     if (!n) return;
-    KLAUNCH(c, K_EMIT, 10.0 * (double)n, k_emit_bwt, bfq_grid(n, 256), 256, rec, n, (u32)(termOut & 0xFF), bwt, qs);
+    u64 ngroups = n / 256 + 1;
+    KLAUNCH(c, K_EMIT, 10.0 * (double)n, k_emit_bwt, bfq_grid(ngroups, 4), 256, rec, n, (u32)(termOut & 0xFF), bwt, qs, gcnt, ngroups);
 }
