@@ -4,8 +4,8 @@
 // (external/bwt2lcp/dna_string_n.hpp:112-185 operator[] / parallel_rank / rank,
 // dna_bwt_n.hpp:80-101 LF) plus a QUAL[] byte and a rankbv lookup for replaced bases
 // (external/rankbv/rankbv.cpp:115-135, bfq_int.cpp:782).  On MI355X the rank queries of
-// ALL rows are answered once, in row order, by k_lf_build (wave-level bit vectors from
-// __ballot + scanned block counters), and tabulated with everything else a walk needs:
+// ALL rows are answered once, in row order, by k_lf_build (per-lane symbol counters packed in a
+// u64 + wave scan + scanned group counters), and tabulated with everything else a walk needs:
 //
 //   one u64 per eBWT row:  bits  0..39  LF(row)           (0 for terminator rows)
 //                          bits 40..42  symbol code       (# 0, A 1, C 2, G 3, N 4, T 5)

@@ -4,10 +4,10 @@
 // the F-array loop of dna_bwt_n.hpp:46-61, LF() of dna_bwt_n.hpp:80-101 and the QUAL
 // array load of bfq_int.cpp:640-651.  Forbidden symbols raise errSymbol
 // (dna_string_n.hpp:87-93 exits 1).
-//   k_lf_count : symbol counts of every 256-row group            (1 B/row read)
+//   k_lf_count : symbol counts of every 256-row group (skipped when k_emit_bwt already made them)
 //   scans      : counts -> occurrences before each group, totals -> F array
-//   k_lf_build : per row F[c] + before-group + before-row-in-group (ballot bit vectors,
-//                popcounts), packed with code and quality          (2 B read, 8 B written)
+//   k_lf_build : per row F[c] + before-group + before-row-in-group (packed counters, wave
+//                scan), packed with code and quality                (2 B read, 8 B written)
 #include "bfq_internal.h"
 #include "bfq_device.h"
 #include "bfq_rank.h"
