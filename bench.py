@@ -197,7 +197,7 @@ def main():
                              for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])[:5] if v["ms"] > 0 and v["alg_bytes"] > 0}
         res = {"metric": "Mbases/s end-to-end (eBWT+cluster+LF)", "value": round(value, 2), "unit": "Mbases/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/u64 integer",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u64",
                "data": "synthetic (seeded generator, 30x coverage, 1% errors, 0.1% N)",
                "config": {"workload": f"{N}x{L}bp synthetic reads per GPU, M={args.M} B={B} -m 5 K=16", "reads_per_gpu": N,
                           "read_len": L, "rows_per_gpu": N * (L + 1), "parallelism": f"{world} independent blocks"},
