@@ -78,16 +78,28 @@ __global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n,
 __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, const u8 *__restrict__ Q8,
                                                     const u64 *__restrict__ text3, u64 n, SortRec out)
 {
-    for (u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x; p < n; p += (u64)gridDim.x * blockDim.x) {
+    // word index / symbol offset of p advance with the grid stride: one division per thread, not per row
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    const u64 sw = stride / BFQ_SYMS_PER_WORD;
+    const u32 so = (u32)(stride - sw * BFQ_SYMS_PER_WORD);
+    u64 p = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 w = p / BFQ_SYMS_PER_WORD;
+    u32 o = (u32)(p - w * BFQ_SYMS_PER_WORD);
+    for (; p < n; p += stride) {
         u32 pc = 0, pq = (u32)'#';
         if (p > 0) {
             pc = T8[p - 1];
             if (pc) pq = Q8[p - 1];
         }
-        u64 k48 = bfq_key48_of(bfq_key_at(text3, p));
+        u32 o3 = o * 3u;
+        u64 hi = (text3[w] << o3) & BFQ_M63;
+        u64 lo = o3 ? (text3[w + 1] >> (63u - o3)) : 0ull;
+        u64 k48 = bfq_key48_of(bfq_mask_key(hi | lo));
         u64 pay = bfq_pack_val(p, pc, pq);
         out.w0[p] = bfq_rec_w0(k48);
         out.w12[p] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(k48, pay);
+        w += sw; o += so;
+        if (o >= BFQ_SYMS_PER_WORD) { o -= BFQ_SYMS_PER_WORD; w++; }
     }
 }
 
