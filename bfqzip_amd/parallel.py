@@ -115,3 +115,71 @@ def gather_blocks(mine, blocks, roff, dist, device=None):
             oq[lo:lo + n] = g[cap + o:cap + o + n]
             o += n
     return ob, oq
+
+
+def main(argv=None):
+    """`torchrun --nproc-per-node G -m bfqzip_amd.parallel in.fastq [in2.fastq -p] -o OUT -t n [--headers] [...]`
+
+    The multi-GPU counterpart of `BFQzip_parallel.py in.fastq -o OUT -t n -0`: same block split, one block per
+    GPU at a time, outputs merged in block order into OUT.fq (or OUT_1.fq / OUT_2.fq with -p).  Without torchrun it
+    runs all blocks on GPU 0."""
+    import argparse, os
+    import torch
+    from . import api, fastq
+    ap = argparse.ArgumentParser(prog="bfqzip_amd.parallel")
+    ap.add_argument("input"); ap.add_argument("input2", nargs="?")
+    ap.add_argument("-o", "--out", required=True)
+    ap.add_argument("-t", "--threads", type=int, default=1, help="number of blocks (BFQzip_parallel.py -t)")
+    ap.add_argument("-p", "--paired", action="store_true")
+    ap.add_argument("--headers", action="store_true")
+    ap.add_argument("-T", dest="k", type=int, default=16); ap.add_argument("-Q", dest="v", default=">")
+    ap.add_argument("--M", type=int, default=2); ap.add_argument("--B", type=int, default=0)
+    a = ap.parse_args(argv)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("BFQ_BACKEND", "nccl")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend)
+    rank = dist.get_rank() if dist else 0
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local) if (dist and dist.get_backend() == "nccl") else None
+    eng = api.Engine(local, k=a.k, m=5, v=ord(a.v), M=a.M, B=a.B)          # -m 5: what BFQzip.py passes (BFQzip.py:215)
+
+    def run(b, q, r):
+        ob, oq, st = eng.run_reads(b, q, r)
+        return ob, oq
+
+    c1 = fastq.read_fastq(a.input)
+    if a.paired and a.input2:
+        c2 = fastq.read_fastq(a.input2)
+        blocks = paired_blocks(c1[:3], c2[:3], a.threads)
+        o1, o2 = [], []
+        for k, (bb, bq, br, n1) in enumerate(blocks):                       # paired: blocks stay on this rank's GPU
+            if k % world != rank:
+                continue
+            ob, oq = run(bb, bq, br)
+            cut = int(br[n1])
+            o1.append((k, fastq.format_fastq(ob[:cut], oq[:cut], br[:n1 + 1])))
+            o2.append((k, fastq.format_fastq(ob[cut:], oq[cut:], (br[n1:] - br[n1]).astype(np.uint64))))
+        if dist:
+            g1 = [None] * world; g2 = [None] * world
+            dist.all_gather_object(g1, o1); dist.all_gather_object(g2, o2)
+            o1 = [x for g in g1 for x in g]; o2 = [x for g in g2 for x in g]
+        if rank == 0:
+            open(a.out + "_1.fq", "wb").write(b"".join(t for _, t in sorted(o1)))
+            open(a.out + "_2.fq", "wb").write(b"".join(t for _, t in sorted(o2)))
+    else:
+        b, q, r, h = c1
+        res = run_blocks(run, b, q, r, a.threads, dist=dist, device=dev)
+        if rank == 0:
+            open(a.out + ".fq", "wb").write(fastq.format_fastq(res[0], res[1], r, h if a.headers else None))
+    eng.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

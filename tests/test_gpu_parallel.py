@@ -42,3 +42,25 @@ def test_two_ranks_real_engine(t, md5):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert got == md5
+
+
+def test_parallel_cli_single_process(tmp_path):
+    """`python -m bfqzip_amd.parallel` without torchrun = all blocks on GPU 0; same files as BFQzip_parallel.py -t n -0."""
+    import subprocess
+    fq = os.path.join(util.GOLDEN, "example.fastq")
+    out = str(tmp_path / "OUT")
+    r = subprocess.run([sys.executable, "-m", "bfqzip_amd.parallel", fq, "-o", out, "-t", "8"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert hashlib.md5(open(out + ".fq", "rb").read()).hexdigest() == "4ada980195fd8d6fb206408c4f892bc6"
+    # paired: reads_1 / reads_2 of the reference's example = the two halves of the "paired" golden input
+    from bfqzip_amd import fastq, parallel
+    b, q, rr, h, *_ = util.golden_set("paired")
+    c1 = parallel.slice_reads(b, q, rr, 0, 100); c2 = parallel.slice_reads(b, q, rr, 100, 200)
+    f1, f2 = str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")
+    open(f1, "wb").write(fastq.format_fastq(*c1, h[:100])); open(f2, "wb").write(fastq.format_fastq(*c2, h[100:]))
+    r = subprocess.run([sys.executable, "-m", "bfqzip_amd.parallel", f1, f2, "-p", "-o", out, "-t", "2"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    assert hashlib.md5(open(out + "_1.fq", "rb").read()).hexdigest() == "0869c40b37c0d1149f7644025b7bffda"
+    assert hashlib.md5(open(out + "_2.fq", "rb").read()).hexdigest() == "26b0df769ae25a5663f953c55d00ab83"
