@@ -6,7 +6,7 @@
 // -- Illumina-binned when B=1, bfq_int.cpp:784-786) and moves to LF(row) until
 // the terminator row.  One step = ONE 8-byte read of the LF table (bfq_rank.h);
 // N walks in flight hide the dependent-load latency; output bytes are collected in
-// registers and stored 8 at a time.
+// registers and stored 16 at a time.
 #include <stdlib.h>
 #include "bfq_internal.h"
 #include "bfq_device.h"
@@ -28,9 +28,13 @@ __global__ __launch_bounds__(256) void k_invert_count(RankIndex R, u64 N, u32 *_
     }
 }
 
-__device__ __forceinline__ void flush_bytes(u8 *dst, u64 from, u64 to, u64 acc)   // bytes [from,to) of the 8-byte word at from&~7
+// bytes [from,to) of the 16-byte chunk at from & ~15 (lo = bytes 0..7, hi = bytes 8..15)
+__device__ __forceinline__ void flush_bytes(u8 *dst, u64 from, u64 to, u64 lo, u64 hi)
 {
-    for (u64 p = from; p < to; p++) dst[p] = (u8)(acc >> (8 * (p & 7)));
+    for (u64 p = from; p < to; p++) {
+        u32 o = (u32)p & 15u;
+        dst[p] = (u8)((o < 8 ? lo : hi) >> (8 * (o & 7u)));
+    }
 }
 
 template <int NT>
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *_
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
         const u64 lo = roff[i], end = roff[i + 1];
         u64 pos = end, j = i;
-        u64 accb = 0, accq = 0;
+        u64 bl = 0, bh = 0, ql = 0, qh = 0;                            // 16 output bytes of each stream
         bool bad = false;
         while (pos > lo) {
             u64 x = NT ? __builtin_nontemporal_load(R.lfq + j) : R.lfq[j];
@@ -51,26 +55,26 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *_
             u32 q = lfq_qual(x);
             if (B) q = bfq_bin8(q);
             --pos;
-            u32 sh = (u32)(pos & 7) * 8;
-            accb |= (u64)sym << sh;
-            accq |= (u64)q << sh;
-            if ((pos & 7) == 0) {                                    // word [pos,pos+8) is complete or clipped by `end`
-                if (pos + 8 <= end) {
-                    *(u64 *)(out_bases + pos) = accb;
-                    *(u64 *)(out_quals + pos) = accq;
+            u32 o = (u32)pos & 15u, sh = (o & 7u) * 8u;
+            if (o < 8) { bl |= (u64)sym << sh; ql |= (u64)q << sh; }
+            else { bh |= (u64)sym << sh; qh |= (u64)q << sh; }
+            if (o == 0) {                                            // chunk [pos,pos+16) is complete or clipped by `end`
+                if (pos + 16 <= end) {
+                    *(ulonglong2 *)(out_bases + pos) = make_ulonglong2(bl, bh);
+                    *(ulonglong2 *)(out_quals + pos) = make_ulonglong2(ql, qh);
                 } else {
-                    flush_bytes(out_bases, pos, end, accb);
-                    flush_bytes(out_quals, pos, end, accq);
+                    flush_bytes(out_bases, pos, end, bl, bh);
+                    flush_bytes(out_quals, pos, end, ql, qh);
                 }
-                accb = 0; accq = 0;
+                bl = bh = ql = qh = 0;
             }
             j = nx;
         }
-        if (!bad && (lo & 7)) {                                      // leading partial word [lo, min(end, align_up(lo)))
-            u64 hi = (lo + 7) & ~7ull;
+        if (!bad && (lo & 15)) {                                     // leading partial chunk [lo, min(end, align_up(lo)))
+            u64 hi = (lo + 15) & ~15ull;
             if (hi > end) hi = end;
-            flush_bytes(out_bases, lo, hi, accb);
-            flush_bytes(out_quals, lo, hi, accq);
+            flush_bytes(out_bases, lo, hi, bl, bh);
+            flush_bytes(out_quals, lo, hi, ql, qh);
         }
         if (!bad && lfq_code(R.lfq[j]) != 0) bad = true;             // read longer than its slot
         if (bad) atomicAdd(&cnt->errInvert, 1ull);
