@@ -32,7 +32,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const T *__restrict__
     u64 base = (u64)blockIdx.x * RS_BLOCK_ELEMS;
     u64 end = base + RS_BLOCK_ELEMS;
     if (end > n) end = n;
-    for (u64 i = base + threadIdx.x; i < end; i += RS_THREADS) {
+    // 16 bytes per lane and load (4 or 2 records); the block base is a multiple of 4 records
+    constexpr int V = 16 / sizeof(T);
+    u64 i = base + (u64)threadIdx.x * V;
+    for (; i + V <= end; i += (u64)RS_THREADS * V) {
+        uint4 x = *(const uint4 *)(dw + i);
+        if (sizeof(T) == 4) {
+            atomicAdd(&wh[w][(x.x >> shift) & 255u], 1u); atomicAdd(&wh[w][(x.y >> shift) & 255u], 1u);
+            atomicAdd(&wh[w][(x.z >> shift) & 255u], 1u); atomicAdd(&wh[w][(x.w >> shift) & 255u], 1u);
+        } else {                                                  // digit in the low word of each u64
+            atomicAdd(&wh[w][(x.x >> shift) & 255u], 1u); atomicAdd(&wh[w][(x.z >> shift) & 255u], 1u);
+        }
+    }
+    for (; i < end; i++) {                                        // at most V-1 records of the last block
         u32 d = (u32)(dw[i] >> shift) & 255u;
         atomicAdd(&wh[w][d], 1u);
     }
