@@ -196,3 +196,34 @@ def test_full_size_properties(engine):
     assert st2 == st                                                        # deterministic
     del db, dq, ob, oq
     torch.cuda.empty_cache()
+
+
+def test_long_and_degenerate_collections(engine, orc):
+    """Reads up to 60 000 bases (LCP held in 16 bits), empty collections, only-empty reads, all-N reads,
+    poly-A (one segment longer than a wavefront with 3 000-symbol ties); reads beyond BFQ_MAX_READ_LEN refused."""
+    rng = np.random.default_rng(5)
+    ACGT = np.array(list(b"ACGT"), np.uint8)
+    g = ACGT[rng.integers(0, 4, 70000)]
+    E = np.zeros(0, np.uint8)
+
+    def mk(reads):
+        b = np.concatenate(reads) if sum(len(x) for x in reads) else E
+        q = rng.integers(33, 74, len(b)).astype(np.uint8)
+        r = np.zeros(len(reads) + 1, np.uint64)
+        r[1:] = np.cumsum([len(x) for x in reads])
+        return b, q, r
+
+    cases = [[g[:9999], g[:20000], g[:60000], g[100:60000], g[:60000].copy(), g[5:9999]],
+             [E] * 5,
+             [np.full(50, ord("N"), np.uint8)] * 40 + [np.full(7, ord("N"), np.uint8)],
+             [E] * 5000 + [ACGT[:1]],
+             [np.full(3000, ord("A"), np.uint8)] * 3 + [np.full(2999, ord("A"), np.uint8)]]
+    for reads in cases:
+        b, q, r = mk(reads)
+        _check_against_oracle(engine, orc, b, q, r, m=2, k=3)
+    b, q, r = mk([])                                                   # no reads at all
+    hb, hq, st = engine.run_reads(b, q, r)
+    assert len(hb) == 0 and st["n_rows"] == 0
+    with pytest.raises(api.BfqError) as e:
+        engine.run_reads(*mk([g[:65001]]))
+    assert e.value.code == -5
