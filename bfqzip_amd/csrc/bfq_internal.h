@@ -22,7 +22,7 @@ struct BfqError {
 
 // ---- kernel ids for the profiler ------------------------------------------------
 enum BfqKernel {
-    K_TEXT = 0, K_PACK, K_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_SEG_FLAGS, K_SEG_COMPACT,
+    K_TEXT = 0, K_PACK, K_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_HUGE_ROUND, K_CLUSTER_BIG,
     K_REFINE_WAVE, K_REFINE_BIG, K_EMIT, K_RANK_BUILD, K_RANK_FINAL, K_LCP_FLAGS, K_CLUSTER_COMPACT, K_CLUSTER,
     K_INVERT_COUNT, K_INVERT, K_SYNTH, K_FASTQ, K_MISC, K_NUM
 };
@@ -42,7 +42,10 @@ struct DevCounters {
     u64 mismatch;        // >0: rebuilt eBWT differs from the given one
     u64 nSegs;           // segments of >= 2 rows met by the refinement
     u64 errFastq;        // >0: a record whose quality line is not as long as its sequence
-    u64 pad[9];
+    u64 hugeCount;       // segments above BFQ_HUGE_SEG rows, left to the radix rounds of k_bigseg.hip
+    u64 hugeRows;        // their rows
+    u64 bigClusters;     // clusters above CL_BIG rows, left to k_cluster_big
+    u64 pad[6];
 };
 
 // the tabulated rank queries: one u64 per eBWT row (layout: bfq_rank.h)
@@ -127,9 +130,12 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
                     u8 *T8, u8 *Q8, u64 *text3, u64 nwords);
 void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out);
 // LSD radix sort of the records on their 48-bit key; result ends in A
-void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n);
+void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes = 6);   // passes even; fewer = low digits only
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
 void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
+// segments above BFQ_HUGE_SEG rows (listed by k_refine_big): whole-device radix rounds on the following symbols
+#define BFQ_HUGE_SEG 4096
+void bfq_refine_huge(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, const u64 *hugeStart, const u64 *hugeLen);
 void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs, u32 *gcnt);   // gcnt: [6][n/256+1] symbol counts
 // whole step 1 on device-resident reads; leaves c->d_bwt/d_qual/d_lcp
 void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,

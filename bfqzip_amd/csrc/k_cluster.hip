@@ -11,6 +11,10 @@
 //                 are disjoint, so each one is handled independently by the thread
 //                 that sits on its first in() row, walking it in row order exactly as
 //                 the reference does (the M=1 double sum keeps its order).
+//   k_cluster_big : clusters longer than CL_BIG rows (low-complexity reads: one cluster can span
+//                 millions of rows) get a whole workgroup: parallel counts, one decision,
+//                 parallel edits.  Same results; only the M=1 double sum stays sequential,
+//                 because its rounding depends on the order.
 // Base replacements are recorded in modsym[r] (0 = untouched) instead of the
 // reference's rankbv bit + BWT_MOD string (bfq_int.cpp:386-387,582-591).
 #include <stdlib.h>
@@ -58,6 +62,7 @@ struct ClusterArgs {
     const double *qthr;     // [qthrN] decreasing: smallest x with round(-10*log10(x)) <= qthrLo+k
     int qthrLo, qthrN;
     DevCounters *cnt;
+    u64 *bigStart;          // first in() rows of the clusters left to k_cluster_big
 };
 
 __device__ __forceinline__ int ord5(u8 c)   // bfq_int.cpp:106-110: A0 C1 G2 T3 N4
@@ -205,6 +210,7 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
 // reference does.  A cluster belongs to the chunk it starts in; its rows may extend past the
 // chunk end.  Statistics (bfq_int.cpp:53-62) stay in per-thread scalars until the kernel ends.
 #define CL_CHUNK 4096
+#define CL_BIG 2048                                  // rows scanned by one thread before a cluster goes to k_cluster_big
 #define CL_WROWS (CL_CHUNK / 4)                       // rows per wave
 __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
 {
@@ -236,6 +242,7 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
             u32 idx = t - (ww == 0 ? 0u : (ww == 1 ? n0 : (ww == 2 ? n0 + n1 : n0 + n1 + n2)));
             u64 r = ch * CL_CHUNK + starts[ww][idx];
             u64 e = r;
+            bool big = false;
             for (;;) {                                              // in[] is padded: 8 flags per 8-byte load
                 u64 x = *(const u64 *)(a.in + e + 1);
                 u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;   // first zero byte
@@ -243,7 +250,9 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
                 if (e + run >= a.n) run = (u32)(a.n - 1 - e);
                 e += run;
                 if (run < 8 || e + 1 >= a.n) break;
+                if (e - r >= CL_BIG) { big = true; break; }
             }
+            if (big) { a.bigStart[atomicAdd(&a.cnt->bigClusters, 1ull)] = r; continue; }
             process_cluster_body(a, r - 1, e, st);
         }
         __syncthreads();
@@ -260,6 +269,168 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
     if (threadIdx.x < 8 && shst[threadIdx.x]) atomicAdd(&a.cnt->stats[threadIdx.x], (u64)shst[threadIdx.x]);
 }
 
+// ---- clusters longer than CL_BIG rows: one workgroup each ------------------------------------
+struct BigShared {
+    u64 freq[5], base;
+    u32 low, sum, mx, fr0, fr1;
+    int mode, newqs;          // mode 0 nothing, 1 mod_smooth towards sym0, 2 two frequent symbols
+    u8 sym0, sym1, prec0, prec1;
+    u64 end;
+};
+
+__device__ void big_cluster(const ClusterArgs &a, u64 start, u64 end, BigShared &sh)
+{
+    const u8 TERM = (u8)a.term;
+    const u32 tid = threadIdx.x;
+    if (tid == 0) {
+        for (int s = 0; s < 5; s++) sh.freq[s] = 0;
+        sh.base = 0; sh.low = 0; sh.sum = 0; sh.mx = 0; sh.fr0 = 0; sh.fr1 = 0; sh.mode = 0;
+    }
+    __syncthreads();
+    {                                                                          // :437-449 counts
+        u32 fA = 0, fC = 0, fG = 0, fT = 0, fN = 0, low = 0, sum = 0;
+        int mx = 0;
+        for (u64 j = start + tid; j <= end; j += 256) {
+            u8 b = a.bwt[j];
+            if (b == TERM) continue;
+            int q = (int)(signed char)a.qual[j];
+            int o = ord5(b);
+            fA += (o == 0); fC += (o == 1); fG += (o == 2); fT += (o == 3); fN += (o == 4);
+            if (q >= a.t + 33) low |= 1u << o;
+            sum += (u32)q;                                                     // wraps like the reference's int
+            if (q > mx) mx = q;
+        }
+        if (fA) atomicAdd(&sh.freq[0], (u64)fA);
+        if (fC) atomicAdd(&sh.freq[1], (u64)fC);
+        if (fG) atomicAdd(&sh.freq[2], (u64)fG);
+        if (fT) atomicAdd(&sh.freq[3], (u64)fT);
+        if (fN) atomicAdd(&sh.freq[4], (u64)fN);
+        if (low) atomicOr(&sh.low, low);
+        atomicAdd(&sh.sum, sum);
+        atomicMax(&sh.mx, (u32)mx);
+    }
+    __syncthreads();
+    if (tid == 0) {                                                            // the decision of :451-580
+        u64 size = end - start + 1;
+        u64 base_num = sh.freq[0] + sh.freq[1] + sh.freq[2] + sh.freq[3] + sh.freq[4];
+        sh.base = base_num;
+        if (size >= (u64)(long long)a.m) {
+            atomicAdd(&a.cnt->stats[0], 1ull);
+            if (base_num) {
+                atomicAdd(&a.cnt->stats[5], base_num);
+                int newqs;
+                if (a.M == 1) {
+                    double sum_err = 0;
+                    for (u64 j = start; j <= end; j++)
+                        if (a.bwt[j] != TERM) sum_err = sum_err + a.powtab[a.qual[j]];
+                    double avg_err = sum_err / (double)base_num;
+                    int lo = 0, hi = a.qthrN - 1;
+                    while (lo < hi) { int mid = (lo + hi) >> 1; if (a.qthr[mid] <= avg_err) hi = mid; else lo = mid + 1; }
+                    int q = a.qthrLo + lo;
+                    newqs = a.ext ? (int)(signed char)(u8)((u8)q + 33) : (int)(signed char)(q + 33);
+                } else if (a.M == 2) {
+                    newqs = (int)(signed char)a.v;
+                } else if (a.M == 3) {
+                    int sum = (int)sh.sum;
+                    if (sum == 0) newqs = 0;
+                    else if (a.ext) newqs = (int)(signed char)(u8)roundf((float)sum / (float)base_num);
+                    else newqs = (int)(signed char)(int)((u64)(long long)sum / base_num);
+                } else {
+                    newqs = (int)sh.mx;
+                }
+                sh.newqs = newqs;
+                u8 Freq[5];
+                int nf = 0, nnn = 0;
+                for (int s = 0; s < 5; s++)
+                    if (sh.freq[s] > 0) {
+                        nnn++;
+                        u32 perc = (u32)((100ull * sh.freq[s]) / base_num) & 0xFFu;
+                        if ((float)perc >= (float)a.f) Freq[nf++] = dna5(s);
+                    }
+                if (nnn == 1) atomicAdd(&a.cnt->stats[4], 1ull);
+                if (nf >= 3) atomicAdd(&a.cnt->errFreq3, 1ull);
+                else if (nf == 0) atomicAdd(&a.cnt->stats[1], 1ull);
+                else if (nf == 1) {
+                    if (Freq[0] == 'N') atomicAdd(&a.cnt->stats[1], 1ull);
+                    else { sh.mode = 1; sh.sym0 = Freq[0]; }
+                } else if (base_num < (u64)(long long)a.m) atomicAdd(&a.cnt->stats[1], 1ull);
+                else if (Freq[0] == 'N') { sh.mode = 1; sh.sym0 = Freq[1]; atomicAdd(&a.cnt->stats[3], 1ull); }
+                else if (Freq[1] == 'N') { sh.mode = 1; sh.sym0 = Freq[0]; atomicAdd(&a.cnt->stats[3], 1ull); }
+                else { sh.mode = 2; sh.sym0 = Freq[0]; sh.sym1 = Freq[1]; }
+            }
+        }
+    }
+    __syncthreads();
+    const int mode = sh.mode, newqs = sh.newqs;
+    const u32 lowQS = sh.low;
+    const u8 s0 = sh.sym0, s1 = sh.sym1;
+    u32 modb = 0, qs = 0;
+    if (mode == 1) {                                                           // :376-405
+        for (u64 j = start + tid; j <= end; j += 256) {
+            u8 b = a.bwt[j];
+            if (b == TERM) continue;
+            if (b != s0 && !((lowQS >> ord5(b)) & 1u)) { set_mod(a, j, s0); modb++; }
+            else if (b == s0) { set_qual(a, j, newqs); qs++; }
+            else if (newqs < (int)(signed char)a.qual[j]) { set_qual(a, j, newqs); qs++; }
+        }
+    } else if (mode == 2) {                                                    // :542-591
+        u32 f0 = 0, f1 = 0;
+        for (u64 j = start + tid; j <= end; j += 256) {
+            u8 b = a.bwt[j];
+            if (b != s0 && b != s1) continue;
+            u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
+            if (ch != TERM && ch != 'N') { if (b == s0) f0 |= 1u << ord5(ch); else f1 |= 1u << ord5(ch); }
+        }
+        if (f0) atomicOr(&sh.fr0, f0);
+        if (f1) atomicOr(&sh.fr1, f1);
+        __syncthreads();
+        f0 = sh.fr0 & 15u; f1 = sh.fr1 & 15u;
+        // with exactly one preceding symbol per frequent base, "the last one seen" is that symbol
+        if (__popc(f0) == 1 && __popc(f1) == 1 && f0 != f1) {
+            const u8 p0 = dna5(__ffs(f0) - 1), p1 = dna5(__ffs(f1) - 1);
+            if (tid == 0) atomicAdd(&a.cnt->stats[3], 1ull);
+            for (u64 j = start + tid; j <= end; j += 256) {
+                u8 b = a.bwt[j];
+                if (b == TERM) continue;
+                if (b != s0 && b != s1 && !((lowQS >> ord5(b)) & 1u)) {
+                    u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
+                    if (ch == p0) { set_mod(a, j, s0); modb++; }
+                    else if (ch == p1) { set_mod(a, j, s1); modb++; }
+                } else if (b == s0 || b == s1) { set_qual(a, j, newqs); qs++; }
+                else if (newqs < (int)(signed char)a.qual[j]) { set_qual(a, j, newqs); qs++; }
+            }
+        } else if (tid == 0) atomicAdd(&a.cnt->stats[2], 1ull);
+    }
+    if (qs) atomicAdd(&a.cnt->stats[6], (u64)qs);
+    if (modb) atomicAdd(&a.cnt->stats[7], (u64)modb);
+}
+
+__global__ __launch_bounds__(256) void k_cluster_big(ClusterArgs a)
+{
+    __shared__ BigShared sh;
+    const u64 nbig = a.cnt->bigClusters;
+    for (u64 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
+        const u64 r = a.bigStart[bi];                               // cluster = [r-1, e], e = last row of the in() run
+        __syncthreads();
+        if (threadIdx.x == 0) sh.end = ~0ull;
+        __syncthreads();
+        for (u64 b0 = r + 1;; b0 += 256 * 8) {
+            u64 i = b0 + (u64)threadIdx.x * 8;
+            u64 found = ~0ull;
+            for (u32 k = 0; k < 8; k++) {
+                u64 x = i + k;
+                if (x >= a.n || !a.in[x]) { found = x; break; }
+            }
+            if (found != ~0ull) atomicMin(&sh.end, found);
+            __syncthreads();
+            bool done = (sh.end != ~0ull);
+            __syncthreads();
+            if (done) break;
+        }
+        big_cluster(a, r - 1, sh.end - 1, sh);
+    }
+}
+
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
 {
     if (!n) return;
@@ -274,6 +445,11 @@ void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual,
     a.m = c->P.m; a.v = c->P.v; a.f = c->P.f; a.t = c->P.t; a.term = c->P.term & 0xFF; a.M = c->P.M; a.ext = c->P.ext;
     a.powtab = c->d_powtab; a.qthr = c->d_qthr; a.qthrLo = c->qthrLo; a.qthrN = c->qthrN;
     a.cnt = c->d_cnt;
+    size_t mk = c->mark();
+    a.bigStart = c->alloc<u64>(n / CL_BIG + 2);
     u64 nchunks = ceil_div(n, CL_CHUNK);
     KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, bfq_grid(nchunks, 1), 256, a, nchunks);
+    // the list length stays on the device: a fixed grid strides over it (usually empty)
+    KLAUNCH(c, K_CLUSTER_BIG, 0.0, k_cluster_big, 1024, 256, a);
+    c->release(mk);
 }

@@ -149,7 +149,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, Sor
 }
 
 // key48 digits: 0,1 in w1 (bits 16..31), 2..5 in w0.  6 passes (even): the result returns to A.
-void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n)
+void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes)
 {
     if (n < 2) return;
     u64 nb = ceil_div(n, RS_BLOCK_ELEMS);
@@ -157,7 +157,7 @@ void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n)
     u32 *hist = c->alloc<u32>(256 * nb);
     u64 *off = c->alloc<u64>(256 * nb);
     SortRec in = A, out = B;
-    for (int pass = 0; pass < 6; pass++) {
+    for (int pass = 0; pass < passes; pass++) {
         const int dw = pass < 2 ? 1 : 0;
         const int shift = pass < 2 ? 16 + 8 * pass : 8 * (pass - 2);
         if (dw)

@@ -17,25 +17,18 @@
 //                      heads and their LCP from the words.
 //   k_refine_big   : segments longer than a wavefront: one workgroup each, ascending-only
 //                    bitonic network over the rows in global memory, full-suffix comparator.
+//                    Segments above BFQ_HUGE_SEG rows (low-complexity reads: poly-A/G tails, short
+//                    tandem repeats) are only listed here and sorted by whole-device radix rounds
+//                    (k_bigseg.hip).
 // LCP convention: common prefix counted on bases only, terminators never match
 // (what bfq_int deduces from the BWT, bfq_int.cpp:139-181,183-300, and what
 // eGap --lcp hands to bfq_ext, bfq_ext.cpp:350-412).
 #include "bfq_internal.h"
 #include "bfq_device.h"
+#include "bfq_rec.h"
 
 #define LCP_PENDING 0xFFFFu
 #define RF_CHUNK 2048                               // rows per wavefront chunk
-
-// row r starts a segment: its 16-symbol key differs from the previous row's, or holds a terminator
-__device__ __forceinline__ bool seg_head(u64 kp, u64 k) { return (k != kp) || bfq_key48_has_term(k); }
-__device__ __forceinline__ u64 rec_key(const SortRec &r, u64 i) { return bfq_rec_key48(r.w0[i], (u32)r.w12[i]); }
-__device__ __forceinline__ u64 rec_pay(const SortRec &r, u64 i) { u64 x = r.w12[i]; return bfq_rec_pay((u32)x, (u32)(x >> 32)); }
-// rows of a segment share the key, so its low half can be rewritten from any of them
-__device__ __forceinline__ void rec_set_pay(const SortRec &r, u64 i, u64 pay)
-{
-    u32 w1 = ((u32)r.w12[i] & 0xFFFF0000u) | (u32)(pay >> 32);
-    r.w12[i] = ((u64)(u32)pay << 32) | w1;
-}
 
 // payload <-> working form: word index (34 bits) | 3*offset (6 bits) << 34 | code << 40 | quality << 43 of p + 16
 __device__ __forceinline__ u64 wo_from_pay(u64 pay)
@@ -230,8 +223,23 @@ __device__ __forceinline__ void big_step(const SortRec &rec, u64 s, u64 g, u64 j
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ biglist, const DevCounters *cnt, SortRec rec,
-                                                    u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n)
+// bitonic network with ascending comparators only: flip (i <-> i^(k-1)) then
+// disperse (i <-> i^j, j = k/4 .. 1); the +inf padding beyond g never moves
+__device__ void big_sort(const SortRec &rec, u64 s, u64 g, const u64 *__restrict__ text3, u16 *__restrict__ lcp)
+{
+    u64 P = 1;
+    while (P < g) P <<= 1;
+    for (u64 k = 2; k <= P; k <<= 1) {
+        big_step(rec, s, g, k - 1, text3);
+        for (u64 j = k >> 2; j >= 1; j >>= 1) big_step(rec, s, g, j, text3);
+    }
+    for (u64 i = 1 + threadIdx.x; i < g; i += 256)
+        lcp[s + i] = (u16)suffix_lcp(text3, bfq_val_pos(rec_pay(rec, s + i - 1)), bfq_val_pos(rec_pay(rec, s + i)));
+}
+
+__global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ biglist, DevCounters *cnt, SortRec rec,
+                                                    u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
+                                                    u64 *__restrict__ hugeStart, u64 *__restrict__ hugeLen)
 {
     __shared__ u64 shEnd;
     const u64 nbig = cnt->bigCount;
@@ -240,26 +248,41 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
         __syncthreads();
         if (threadIdx.x == 0) shEnd = ~0ull;
         __syncthreads();
-        for (u64 b0 = s + 1;; b0 += 256) {             // first head after s = end of the segment
-            u64 i = b0 + threadIdx.x;
-            bool h = (i >= n) ? true : seg_head(rec_key(rec, i - 1), rec_key(rec, i));
-            if (h) atomicMin(&shEnd, i);
+        for (u64 b0 = s + 1;; b0 += 256 * 8) {         // first head after s = end of the segment
+            u64 i0 = b0 + (u64)threadIdx.x * 8;
+            u64 kp = (i0 < n) ? rec_key(rec, i0 - 1) : 0ull;
+            for (u32 k = 0; k < 8; k++) {
+                u64 i = i0 + k;
+                if (i >= n) { atomicMin(&shEnd, i); break; }
+                u64 kc = rec_key(rec, i);
+                if (seg_head(kp, kc)) { atomicMin(&shEnd, i); break; }
+                kp = kc;
+            }
             __syncthreads();
             bool done = (shEnd != ~0ull);
             __syncthreads();
             if (done) break;                           // uniform
         }
         const u64 g = shEnd - s;
-        u64 P = 1;
-        while (P < g) P <<= 1;
-        // bitonic network with ascending comparators only: flip (i <-> i^(k-1)) then
-        // disperse (i <-> i^j, j = k/4 .. 1); the +inf padding beyond g never moves
-        for (u64 k = 2; k <= P; k <<= 1) {
-            big_step(rec, s, g, k - 1, text3);
-            for (u64 j = k >> 2; j >= 1; j >>= 1) big_step(rec, s, g, j, text3);
+        if (g > BFQ_HUGE_SEG) {                        // uniform: left to the radix rounds
+            if (threadIdx.x == 0) {
+                u64 h = atomicAdd(&cnt->hugeCount, 1ull);
+                atomicAdd(&cnt->hugeRows, g);
+                hugeStart[h] = s; hugeLen[h] = g;
+            }
+            continue;
         }
-        for (u64 i = 1 + threadIdx.x; i < g; i += 256)
-            lcp[s + i] = (u16)suffix_lcp(text3, bfq_val_pos(rec_pay(rec, s + i - 1)), bfq_val_pos(rec_pay(rec, s + i)));
+        big_sort(rec, s, g, text3, lcp);
+    }
+}
+
+// the same network for listed segments of known length (huge segments that did not fit the radix rounds' workspace)
+__global__ __launch_bounds__(256) void k_refine_listed(const u64 *__restrict__ start, const u64 *__restrict__ len, u64 count, SortRec rec,
+                                                       u16 *__restrict__ lcp, const u64 *__restrict__ text3)
+{
+    for (u64 bi = blockIdx.x; bi < count; bi += gridDim.x) {
+        __syncthreads();
+        big_sort(rec, start[bi], len[bi], text3, lcp);
     }
 }
 
@@ -305,10 +328,18 @@ void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_
     const double lavg = c->N ? (double)(n - c->N) / (double)c->N : 0.0;
     KLAUNCH(c, K_REFINE_WAVE, (3.0 * (lavg + 1.0) / 16.0 + 9.0) * (double)n, k_refine_chunk, bfq_grid(nchunks, 4), 256, rec, lcp, text3, n, biglist,
             c->d_cnt, nchunks);
+    u64 *hugeStart = c->alloc<u64>(n / BFQ_HUGE_SEG + 2), *hugeLen = c->alloc<u64>(n / BFQ_HUGE_SEG + 2);
     // the list length stays on the device: a fixed grid strides over it (usually empty)
-    KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, 1024, 256, (const u64 *)biglist, (const DevCounters *)c->d_cnt, rec, lcp,
-            text3, n);
+    KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, 1024, 256, (const u64 *)biglist, c->d_cnt, rec, lcp, text3, n, hugeStart, hugeLen);
+    bfq_refine_huge(c, rec, text3, n, lcp, hugeStart, hugeLen);
     c->release(m);
+}
+
+void bfq_refine_bitonic(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, const u64 *d_start, const u64 *d_len, u64 count)
+{
+    (void)n;
+    if (!count) return;
+    KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_listed, (unsigned)(count < 1024 ? count : 1024), 256, d_start, d_len, count, rec, lcp, text3);
 }
 
 void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs, u32 *gcnt)

@@ -227,3 +227,47 @@ def test_long_and_degenerate_collections(engine, orc):
     with pytest.raises(api.BfqError) as e:
         engine.run_reads(*mk([g[:65001]]))
     assert e.value.code == -5
+
+
+def _low_complexity(rng):
+    """Poly-A tails, a dinucleotide repeat, noisy poly-G and ordinary reads: ~0.9 M rows, most of them in a few
+    equal-prefix segments of 10^5 rows and in clusters just as long."""
+    ACGT = np.array(list(b"ACGT"), np.uint8)
+    reads = []
+    for _ in range(6000):
+        reads.append(np.full(int(rng.integers(30, 101)), ord("A"), np.uint8))
+    for _ in range(2500):
+        L = int(rng.integers(40, 101)); ph = int(rng.integers(0, 2))
+        s = np.array([ord("A"), ord("C")], np.uint8)[(np.arange(L) + ph) % 2]
+        e = rng.random(L) < 0.01; s[e] = ACGT[rng.integers(0, 4, int(e.sum()))]
+        reads.append(s)
+    for _ in range(2500):
+        L = int(rng.integers(20, 101))
+        s = np.full(L, ord("G"), np.uint8)
+        e = rng.random(L) < 0.02; s[e] = ACGT[rng.integers(0, 4, int(e.sum()))]
+        s[rng.random(L) < 0.005] = ord("N")
+        reads.append(s)
+    g = ACGT[rng.integers(0, 4, 3000)]
+    for _ in range(2000):
+        st = int(rng.integers(0, 2900)); s = g[st:st + 100].copy()
+        if rng.random() < 0.3:
+            s[int(rng.integers(30, 80)):] = ord("A")
+        reads.append(s)
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    b = np.concatenate(reads)
+    q = rng.integers(33, 74, len(b)).astype(np.uint8)
+    r = np.zeros(len(reads) + 1, np.uint64)
+    r[1:] = np.cumsum([len(x) for x in reads])
+    return b, q, r
+
+
+def test_low_complexity_collections(engine, orc, monkeypatch):
+    """Segments and clusters of 10^5 rows (k_bigseg.hip's radix rounds, k_cluster_big) in every mode; then the same
+    with the rounds' slot budget cut down (BFQ_HUGE_CAP) so that batching and the one-workgroup route for
+    segments beyond the budget run too."""
+    b, q, r = _low_complexity(np.random.default_rng(7))
+    for M in range(4):
+        st = _check_against_oracle(engine, orc, b, q, r, M=M, B=M & 1, m=5)
+    assert st["n_big_segments"] > 0
+    monkeypatch.setenv("BFQ_HUGE_CAP", "60000")
+    _check_against_oracle(engine, orc, b, q, r, m=2, k=20)
