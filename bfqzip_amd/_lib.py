@@ -15,7 +15,8 @@ SYMBOLS = [
     "bfq_default_params", "bfq_create", "bfq_create_error", "bfq_destroy", "bfq_set_params",
     "bfq_last_error", "bfq_stream", "bfq_device_count", "bfq_build_ebwt", "bfq_count_reads",
     "bfq_smooth_invert", "bfq_run_reads", "bfq_run_reads_device", "bfq_fetch_ebwt",
-    "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_smooth_invert_fastq",
+    "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_fastq_run_streams",
+    "bfq_smooth_invert_fastq",
     "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device",
     "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
     "bfq_workspace_bytes", "bfq_version",
@@ -89,6 +90,8 @@ def lib():
         L.bfq_fastq_out_bound.argtypes = [u64, u64, u64]
         L.bfq_fastq_build_ebwt.argtypes = [vp, vp, u64, C.c_int, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
         L.bfq_fastq_run.argtypes = [vp, vp, u64, C.c_int, vp, u64, C.POINTER(u64), C.POINTER(Stats)]
+        L.bfq_fastq_run_streams.argtypes = [vp, vp, u64, vp, vp, u64, C.POINTER(u64), vp, u64, C.POINTER(u64),
+                                            C.POINTER(Stats)]
         L.bfq_smooth_invert_fastq.argtypes = [vp, vp, vp, vp, C.c_int, u64, vp, u64, vp, u64, C.POINTER(u64),
                                               C.POINTER(Stats)]
         L.bfq_synth_default.argtypes = [C.POINTER(Synth), u64, C.c_uint32]

@@ -129,6 +129,20 @@ class Engine:
                                       C.byref(ol), C.byref(st)))
         return out[:ol.value].tobytes(), st.as_dict()
 
+    def fastq_run_streams(self, text, want_headers=True):
+        """The whole path with the result as the streams of BFQzip.py --m2/--m3 (BFQzip.py:19-21,192-251):
+        (OUT.fq.dna bytes, OUT.fq.qs bytes, OUT.h bytes or None, stats)."""
+        buf = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+        cap = len(buf) + 16
+        dna = np.empty(cap, np.uint8); qs = np.empty(cap, np.uint8)
+        hdr = np.empty(cap, np.uint8) if want_headers else None
+        sl = C.c_uint64(0); hl = C.c_uint64(0)
+        st = _lib.Stats()
+        self._ck(self.L.bfq_fastq_run_streams(self.h, _ptr(buf), len(buf), _ptr(dna), _ptr(qs), cap, C.byref(sl),
+                                              _ptr(hdr) if want_headers else None, cap, C.byref(hl), C.byref(st)))
+        return (dna[:sl.value].tobytes(), qs[:sl.value].tobytes(),
+                hdr[:hl.value].tobytes() if want_headers else None, st.as_dict())
+
     def smooth_invert_fastq(self, bwt, qs, lcp=None, headers=None):
         """bfq_int / bfq_ext writing the FASTQ text; headers = bytes of the -H file or None."""
         bwt = np.ascontiguousarray(bwt, np.uint8); qs = np.ascontiguousarray(qs, np.uint8)

@@ -549,6 +549,39 @@ extern "C" int bfq_fastq_run(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, i
     });
 }
 
+extern "C" int bfq_fastq_run_streams(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, uint8_t *h_dna, uint8_t *h_qs,
+                                     uint64_t cap_stream, uint64_t *stream_len, uint8_t *h_hdr, uint64_t cap_hdr,
+                                     uint64_t *hdr_len, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        if (st) memset(st, 0, sizeof *st);
+        DevText txt;
+        fastq_upload_and_reserve(c, h_fastq, len, txt);
+        c->zeroCounters();
+        u8 *d_fq = txt.p;
+        DevFastq fq;
+        bfq_fastq_parse(c, d_fq, len, &fq);
+        u8 *ob = c->alloc<u8>(fq.total + 64), *oq = c->alloc<u8>(fq.total + 64);
+        size_t m = c->mark();
+        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
+        steps234_device(c, fq.roff, ob, oq);
+        c->release(m);
+        u8 *d_dna = nullptr, *d_qs = nullptr, *d_hdr = nullptr;
+        u64 hl = 0, sl = fq.total + fq.N;
+        bfq_fastq_streams(c, ob, oq, fq.roff, fq.N, fq.total, d_fq, &fq, &d_dna, &d_qs, h_hdr ? &d_hdr : nullptr, &hl);
+        if (stream_len) *stream_len = sl;
+        if (hdr_len) *hdr_len = hl;
+        if (sl > cap_stream || (h_hdr && hl > cap_hdr)) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
+        if (sl && h_dna) HIP_CHECK(hipMemcpyAsync(h_dna, d_dna, sl, hipMemcpyDeviceToHost, c->stream));
+        if (sl && h_qs) HIP_CHECK(hipMemcpyAsync(h_qs, d_qs, sl, hipMemcpyDeviceToHost, c->stream));
+        if (hl && h_hdr) HIP_CHECK(hipMemcpyAsync(h_hdr, d_hdr, hl, hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+        fill_stats(c, st);
+    });
+}
+
 extern "C" int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp,
                                        int lcp_bytes, uint64_t n, const uint8_t *h_headers, uint64_t headers_len,
                                        uint8_t *h_out, uint64_t cap, uint64_t *out_len, bfq_stats *st)

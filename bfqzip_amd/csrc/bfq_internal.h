@@ -156,3 +156,5 @@ struct DevFastq { u64 N, total; void *rec; u64 *roff; u8 *bases, *quals; u64 *li
 void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq);
 u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, int mode, const u8 *d_hdr,
                      u64 hdrLen, const DevFastq *fq, u8 **d_out);
+void bfq_fastq_streams(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, const u8 *d_fastq,
+                       const DevFastq *fq, u8 **d_dna, u8 **d_qs, u8 **d_hdr, u64 *hdrLen);

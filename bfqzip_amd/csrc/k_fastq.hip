@@ -9,6 +9,8 @@
 //                             (CR before LF stripped; len(DNA) != len(QS) is an error, checkFASTQ.py:18-32)
 //   k_fq_gather             : lines 2 and 4 -> bases / quals back to back (one wave per read)
 //   k_fq_format             : header line (verbatim, or "@"), bases, "+", quals (one wave per read)
+//   k_fq_lines / k_fq_hdr_gather : the separate streams of BFQzip.py --m2/--m3 (OUT.fq.dna, OUT.fq.qs, OUT.h):
+//                             every read's bases / qualities / header as one line each
 #include "bfq_internal.h"
 #include "bfq_device.h"
 
@@ -140,6 +142,34 @@ __global__ __launch_bounds__(256) void k_fq_format(const u8 *__restrict__ bases,
     }
 }
 
+// dna[roff[i] + i ..] = bases of read i + '\n'; same for the qualities (what `sed -n 2~4p` / `4~4p` cut from OUT.fq)
+__global__ __launch_bounds__(256) void k_fq_lines(const u8 *__restrict__ bases, const u8 *__restrict__ quals,
+                                                  const u64 *__restrict__ roff, u64 N, u8 *__restrict__ dna, u8 *__restrict__ qs)
+{
+    u32 lane = bfq_lane();
+    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
+        u64 b = roff[i], L = roff[i + 1] - b, o = b + i;
+        for (u64 k = lane; k < L; k += 64) { dna[o + k] = bases[b + k]; qs[o + k] = quals[b + k]; }
+        if (lane == 0) { dna[o + L] = 10; qs[o + L] = 10; }
+    }
+}
+__global__ __launch_bounds__(256) void k_fq_hdrsize(const FqRec *__restrict__ rec, u64 N, u32 *__restrict__ sizes)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) sizes[i] = rec[i].hdrLen + 1;
+}
+__global__ __launch_bounds__(256) void k_fq_hdr_gather(const u8 *__restrict__ buf, const FqRec *__restrict__ rec,
+                                                       const u64 *__restrict__ hOff, u64 N, u8 *__restrict__ out)
+{
+    u32 lane = bfq_lane();
+    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
+        u64 s = rec[i].hdrStart, hl = rec[i].hdrLen, o = hOff[i];
+        for (u64 k = lane; k < hl; k += 64) out[o + k] = buf[s + k];
+        if (lane == 0) out[o + hl] = 10;
+    }
+}
+
 // positions of the line ends of a text resident on the device; a last line without newline gets a
 // virtual end at `len`.  *nlines = number of lines.
 static u64 *line_index(bfq_ctx *c, const u8 *d_buf, u64 len, u64 *nlines)
@@ -245,4 +275,26 @@ u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     }
     *d_out = out;
     return outLen;
+}
+
+// The streams of BFQzip.py --m2/--m3: *d_dna / *d_qs hold total + N bytes each; *d_hdr (when asked for) the
+// header lines of the parsed FASTQ `fq`, *hdrLen bytes.
+void bfq_fastq_streams(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, const u8 *d_fastq,
+                       const DevFastq *fq, u8 **d_dna, u8 **d_qs, u8 **d_hdr, u64 *hdrLen)
+{
+    u8 *dna = c->alloc<u8>(total + N + 64), *qs = c->alloc<u8>(total + N + 64);
+    u64 waves = N < (1u << 18) ? N : (1u << 18);
+    if (N) KLAUNCH(c, K_FASTQ, 4.0 * (double)total + 2.0 * (double)N, k_fq_lines, ceil_div(waves, 4), 256, d_bases, d_quals, d_roff, N, dna, qs);
+    *d_dna = dna; *d_qs = qs;
+    if (!d_hdr) return;
+    u32 *sizes = c->alloc<u32>(N + 1);
+    u64 *hOff = c->alloc<u64>(N + 2);
+    if (N) KLAUNCH(c, K_FASTQ, 28.0 * (double)N, k_fq_hdrsize, bfq_grid(N, 256), 256, (const FqRec *)fq->rec, N, sizes);
+    bfq_exscan_u32(c, sizes, hOff, N, hOff + N);
+    u64 hl = 0;
+    HIP_CHECK(hipMemcpyAsync(&hl, hOff + N, sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    u8 *hdr = c->alloc<u8>(hl + 64);
+    if (N) KLAUNCH(c, K_FASTQ, 2.0 * (double)hl, k_fq_hdr_gather, ceil_div(waves, 4), 256, d_fastq, (const FqRec *)fq->rec, (const u64 *)hOff, N, hdr);
+    *d_hdr = hdr; *hdrLen = hl;
 }

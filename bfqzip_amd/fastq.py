@@ -56,3 +56,15 @@ def format_fastq(bases, quals, roff, headers=None):
         out += (headers[i] if headers is not None else b"@") + b"\n"
         out += bb[s:e] + b"\n+\n" + qq[s:e] + b"\n"
     return bytes(out)
+
+
+def format_lines(data, roff):
+    """One line per read (`sed -n 2~4p` / `4~4p` of the FASTQ, BFQzip.py:20-21): the streams OUT.fq.dna / OUT.fq.qs."""
+    roff = np.asarray(roff, np.int64)
+    n = len(roff) - 1
+    out = np.full(int(roff[-1]) + n, 10, np.uint8)
+    if len(data):
+        lens = np.diff(roff)
+        dst = np.arange(int(roff[-1]), dtype=np.int64) + np.repeat(np.arange(n, dtype=np.int64), lens)
+        out[dst] = np.asarray(data, np.uint8)[:int(roff[-1])]
+    return out.tobytes()

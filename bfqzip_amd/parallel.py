@@ -132,6 +132,8 @@ def main(argv=None):
     ap.add_argument("-t", "--threads", type=int, default=1, help="number of blocks (BFQzip_parallel.py -t)")
     ap.add_argument("-p", "--paired", action="store_true")
     ap.add_argument("--headers", action="store_true")
+    ap.add_argument("--m2", action="store_true", help="also write OUT.fq.dna and OUT.fq.qs (BFQzip.py:231-249)")
+    ap.add_argument("--m3", action="store_true", help="--m2 plus OUT.h (BFQzip.py:195-201)")
     ap.add_argument("-T", dest="k", type=int, default=16); ap.add_argument("-Q", dest="v", default=">")
     ap.add_argument("--M", type=int, default=2); ap.add_argument("--B", type=int, default=0)
     a = ap.parse_args(argv)
@@ -175,6 +177,11 @@ def main(argv=None):
         res = run_blocks(run, b, q, r, a.threads, dist=dist, device=dev)
         if rank == 0:
             open(a.out + ".fq", "wb").write(fastq.format_fastq(res[0], res[1], r, h if a.headers else None))
+            if a.m2 or a.m3:
+                open(a.out + ".fq.dna", "wb").write(fastq.format_lines(res[0], r))
+                open(a.out + ".fq.qs", "wb").write(fastq.format_lines(res[1], r))
+            if a.m3:
+                open(a.out + ".h", "wb").write(b"".join(x + b"\n" for x in h))
     eng.close()
     if dist:
         dist.barrier()

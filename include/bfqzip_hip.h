@@ -109,6 +109,10 @@ int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_qu
  *                            header line through (BFQzip.py --headers), else "@" (bfq_int.cpp:758,805).
  *   bfq_smooth_invert_fastq: bfq_int / bfq_ext writing the FASTQ text itself; h_headers = the -H file
  *                            (one line per read) or NULL.
+ *   bfq_fastq_run_streams  : the whole path with the result as the separate streams that BFQzip.py's
+ *                            --m2/--m3 modes compress (BFQzip.py:19-21,192-251): h_dna = `sed -n 2~4p OUT.fq`,
+ *                            h_qs = `sed -n 4~4p OUT.fq` (total bases + reads bytes each), h_hdr = `sed -n 1~4p
+ *                            in.fastq` (may be NULL).  A capacity of `len` is always enough for each.
  * Output size: bfq_fastq_out_bound(total bases, reads, header bytes without newlines or 0). */
 uint64_t bfq_fastq_out_bound(uint64_t total_bases, uint64_t n_reads, uint64_t header_bytes);
 int bfq_fastq_build_ebwt(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int term_out,
@@ -116,6 +120,9 @@ int bfq_fastq_build_ebwt(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int t
                          uint64_t *n_rows, uint64_t *n_reads);
 int bfq_fastq_run(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int keep_headers,
                   uint8_t *h_out, uint64_t cap, uint64_t *out_len, bfq_stats *st);
+int bfq_fastq_run_streams(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len,
+                          uint8_t *h_dna, uint8_t *h_qs, uint64_t cap_stream, uint64_t *stream_len,
+                          uint8_t *h_hdr, uint64_t cap_hdr, uint64_t *hdr_len, bfq_stats *st);
 int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs,
                             const void *h_lcp, int lcp_bytes, uint64_t n,
                             const uint8_t *h_headers, uint64_t headers_len,

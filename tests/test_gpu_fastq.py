@@ -35,6 +35,25 @@ def test_fastq_run_text_to_text(engine, name):
         assert sth == st
 
 
+@pytest.mark.parametrize("name", list(IDX))
+def test_fastq_run_streams(engine, name):
+    """OUT.fq.dna / OUT.fq.qs / OUT.h of BFQzip.py --m2/--m3 = `sed -n 2~4p / 4~4p` of the reference's OUT.fq
+    (golden, written by the compiled bfq_int) and `sed -n 1~4p` of the input (BFQzip.py:19-21,192-251)."""
+    engine.set_params(m=5)
+    dna, qs, hdr, st = engine.fastq_run_streams(_raw(name))
+    ref = open(os.path.join(util.GOLDEN, name + ".M2B0.fq"), "rb").read().split(b"\n")[:-1]
+    assert dna == b"".join(x + b"\n" for x in ref[1::4])
+    assert qs == b"".join(x + b"\n" for x in ref[3::4])
+    lines = _raw(name).split(b"\n")
+    if lines[-1] == b"":
+        lines.pop()
+    assert hdr == b"".join(x + b"\n" for x in lines[0::4])
+    d2, q2, h2, st2 = engine.fastq_run_streams(_raw(name), want_headers=False)
+    assert h2 is None and d2 == dna and q2 == qs and st2 == st
+    d0, q0, h0, _ = engine.fastq_run_streams(b"")
+    assert d0 == b"" and q0 == b"" and h0 == b""
+
+
 def test_smooth_invert_fastq_with_header_file(engine):
     name = "example"
     b, q, r, h, bwt, qs, lcp = util.golden_set(name)

@@ -53,6 +53,10 @@ def test_fastq_roundtrip_and_validation():
         fastq.parse_fastq_bytes(b"@r\nACGT\n+\n")
     b2, q2, r2, _ = fastq.parse_fastq_bytes(b"@a\nAC\n+\nII\n@b\n\n+\n\n@c\nG\n+\nI")   # empty read, no final newline
     assert list(r2) == [0, 2, 2, 3] and b2.tobytes() == b"ACG"
+    lines = raw.split(b"\n")
+    assert fastq.format_lines(b, r) == b"".join(x + b"\n" for x in lines[1::4])      # sed -n 2~4p (BFQzip.py:21)
+    assert fastq.format_lines(q, r) == b"".join(x + b"\n" for x in lines[3::4])
+    assert fastq.format_lines(b2, r2) == b"AC\n\nG\n" and fastq.format_lines(b[:0], r[:1]) == b""
 
 
 def test_synthetic_generator_is_seeded_and_shaped():
