@@ -14,8 +14,11 @@
 #include "bfq_internal.h"
 #include "bfq_device.h"
 
+#ifndef RS_THREADS
 #define RS_THREADS 256
-#define RS_WAVES 4
+#endif
+#define RS_WAVES (RS_THREADS / 64)
+#define RS_OCC (1024 / RS_THREADS)                  // workgroups per CU (16 waves); 512-thread tiles measured 40 % slower
 #define RS_ROUNDS 12                                // items per thread
 #define RS_TILE (RS_THREADS * RS_ROUNDS)            // 3072 records per tile
 #define RS_TILES_PER_BLOCK 8
@@ -50,12 +53,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const T *__restrict__
     }
     __syncthreads();
     u32 d = threadIdx.x;
-    hist[(u64)d * nblocks + blockIdx.x] = wh[0][d] + wh[1][d] + wh[2][d] + wh[3][d];
+    if (d < 256) {
+        u32 t = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) t += wh[k][d];
+        hist[(u64)d * nblocks + blockIdx.x] = t;
+    }
 }
 
 // DW = which word carries the digit of this pass (0: w0, 1: w1)
 template <int DW>
-__global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, SortRec out, u64 n, int shift,
+__global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in, SortRec out, u64 n, int shift,
                                                               const u64 *__restrict__ blockOff, u64 nblocks)
 {
     __shared__ u64 stage[RS_TILE];          // w0, then the (w1,w2) pair of the records
@@ -63,11 +71,11 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, Sor
     __shared__ u32 wcnt[RS_WAVES][256];     // per-wave digit counters -> exclusive prefix across waves
     __shared__ u32 lstart[256];             // first tile-sorted slot of each digit
     __shared__ u64 gbase[256];              // global output cursor of each digit for this workgroup
-    __shared__ u32 shscan[4];
+    __shared__ u32 shscan[RS_WAVES];
 
     const u32 tid = threadIdx.x, lane = bfq_lane(), w = tid >> 6;
     const u64 ltmask = bfq_lanemask_lt();
-    gbase[tid] = blockOff[(u64)tid * nblocks + blockIdx.x];
+    if (tid < 256) gbase[tid] = blockOff[(u64)tid * nblocks + blockIdx.x];
 
     for (int t = 0; t < RS_TILES_PER_BLOCK; t++) {
         u64 tbase = (u64)blockIdx.x * RS_BLOCK_ELEMS + (u64)t * RS_TILE;
@@ -109,11 +117,20 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, Sor
         __syncthreads();
 
         // per digit (thread = digit): prefix across waves, then across digits
-        u32 c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-        u32 tot = c0 + c1 + c2 + c3, dummy;
-        wcnt[0][tid] = 0; wcnt[1][tid] = c0; wcnt[2][tid] = c0 + c1; wcnt[3][tid] = c0 + c1 + c2;
-        u32 ls = bfq_block_exscan32(tot, shscan, &dummy);        // two barriers inside
-        lstart[tid] = ls;
+        u32 tot = 0;
+        if (tid < 256) {
+#pragma unroll
+            for (int k = 0; k < RS_WAVES; k++) { u32 ck = wcnt[k][tid]; wcnt[k][tid] = tot; tot += ck; }
+        }
+        {                                                        // exclusive scan of tot over the workgroup
+            u32 inc = bfq_wave_incscan32(tot);
+            if (lane == 63) shscan[w] = inc;
+            __syncthreads();
+            u32 base = 0;
+#pragma unroll
+            for (int k = 0; k < RS_WAVES; k++) base += (k < (int)w) ? shscan[k] : 0u;
+            if (tid < 256) lstart[tid] = base + inc - tot;
+        }
         __syncthreads();
 
 #pragma unroll
@@ -143,7 +160,7 @@ __global__ __launch_bounds__(RS_THREADS, 4) void k_radix_scatter(SortRec in, Sor
             if (j < cnt) out.w12[dst[q]] = stage[j];
         }
         __syncthreads();
-        gbase[tid] += tot;
+        if (tid < 256) gbase[tid] += tot;
         // next iteration starts with a barrier after zeroing wcnt
     }
 }
