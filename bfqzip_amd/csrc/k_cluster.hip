@@ -102,35 +102,50 @@ __device__ __forceinline__ void mod_smooth(const ClusterArgs &a, u64 start, u64 
     }
 }
 
-__device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 start, u64 end, ClStat &st)
+// One cluster starting at row `start` (= first in() row - 1).  Its extent comes out of the same walk that
+// counts it: row j > start belongs while in[start+1..j] are all set.  Returns true (nothing done) when the
+// cluster outgrows CL_BIG rows: those go to k_cluster_big.
+#define CL_BIG 2048
+__device__ __forceinline__ bool process_cluster_body(const ClusterArgs &a, u64 start, ClStat &st)
 {
     const u8 TERM = (u8)a.term;
-    u64 size = end - start + 1;
-    if (size < (u64)(long long)a.m) return;                                   // :422
     u32 freqs[5] = {0, 0, 0, 0, 0};
     u32 lowQS = 0;
     u64 base_num = 0;
-    for (u64 j0 = start; j0 <= end; j0 += 8) {                                 // :437-449, 8 rows per 8-byte load
+    int sum = 0, mx = 0;                                                       // :323-338 avg_qs, :342-353 max_qs
+    double sum_err = 0;                                                        // :357-373 mean_error (row order kept)
+    u64 end;
+    for (u64 j0 = start;; j0 += 8) {                                           // :437-449, 8 rows per 8-byte load
+        u64 xin = *(const u64 *)(a.in + j0 + 1);                               // in() of rows j0+1 .. j0+8 (in[] is padded)
+        u64 z = (xin - 0x0101010101010101ull) & ~xin & 0x8080808080808080ull;  // first zero byte
+        u32 run = z ? (u32)(__builtin_ctzll(z) >> 3) : 8u;
+        if (j0 + run >= a.n) run = (u32)(a.n - 1 - j0);
+        u32 cnt = run < 8 ? run + 1 : 8u;                                      // rows j0 .. j0+cnt-1 are inside
         u64 xb = *(const u64 *)(a.bwt + j0), xq = *(const u64 *)(a.qual + j0);
-        u32 cnt = (end - j0 + 1 < 8) ? (u32)(end - j0 + 1) : 8u;
         for (u32 k = 0; k < cnt; k++) {
             u8 b = (u8)(xb >> (8 * k));
             if (b != TERM) {
                 int o = ord5(b);
+                u8 qb = (u8)(xq >> (8 * k));
+                int q = (int)(signed char)qb;
                 freqs[o]++; base_num++;
-                if ((int)(signed char)(u8)(xq >> (8 * k)) >= a.t + 33) lowQS |= 1u << o;
+                if (q >= a.t + 33) lowQS |= 1u << o;
+                sum += q;
+                if (q > mx) mx = q;
+                if (a.M == 1) sum_err = sum_err + a.powtab[qb];
             }
         }
+        if (run < 8) { end = j0 + run; break; }
+        if (j0 + 8 - start >= CL_BIG) return true;
     }
+    u64 size = end - start + 1;
+    if (size < (u64)(long long)a.m) return false;                             // :422
     st.clust++;
-    if (base_num == 0) return;                                                 // :453
+    if (base_num == 0) return false;                                           // :453
     st.bases += (u32)base_num;
 
     int newqs;
-    if (a.M == 1) {                                                            // :357-373 mean_error
-        double sum_err = 0;
-        for (u64 j = start; j <= end; j++)
-            if (a.bwt[j] != TERM) sum_err = sum_err + a.powtab[a.qual[j]];
+    if (a.M == 1) {
         double avg_err = sum_err / (double)base_num;
         int lo = 0, hi = a.qthrN - 1;                                          // first k with qthr[k] <= avg_err
         while (lo < hi) { int mid = (lo + hi) >> 1; if (a.qthr[mid] <= avg_err) hi = mid; else lo = mid + 1; }
@@ -138,17 +153,11 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
         newqs = a.ext ? (int)(signed char)(u8)((u8)q + 33) : (int)(signed char)(q + 33);
     } else if (a.M == 2) {
         newqs = (int)(signed char)a.v;                                         // :467
-    } else if (a.M == 3) {                                                     // :323-338 avg_qs
-        int sum = 0;
-        for (u64 j = start; j <= end; j++)
-            if (a.bwt[j] != TERM) sum += (int)(signed char)a.qual[j];
+    } else if (a.M == 3) {
         if (sum == 0) newqs = 0;
         else if (a.ext) newqs = (int)(signed char)(u8)roundf((float)sum / (float)base_num);   // bfq_ext.cpp:496
         else newqs = (int)(signed char)(int)((u64)(long long)sum / base_num);
-    } else {                                                                   // :342-353 max_qs
-        int mx = 0;
-        for (u64 j = start; j <= end; j++)
-            if (a.bwt[j] != TERM) { int q = (int)(signed char)a.qual[j]; if (q > mx) mx = q; }
+    } else {
         newqs = mx;
     }
 
@@ -161,17 +170,17 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
             if ((float)perc >= (float)a.f) Freq[nf++] = dna5(s);
         }
     if (nnn == 1) st.alleq++;
-    if (nf >= 3) { atomicAdd(&a.cnt->errFreq3, 1ull); return; }               // :505 assert
+    if (nf >= 3) { atomicAdd(&a.cnt->errFreq3, 1ull); return false; }               // :505 assert
 
-    if (nf == 0) { st.disc++; return; }
+    if (nf == 0) { st.disc++; return false; }
     if (nf == 1) {
         if (Freq[0] == 'N') st.disc++;
         else mod_smooth(a, start, end, Freq[0], newqs, lowQS, st);
-        return;
+        return false;
     }
-    if (base_num < (u64)(long long)a.m) { st.disc++; return; }                   // :520
-    if (Freq[0] == 'N') { mod_smooth(a, start, end, Freq[1], newqs, lowQS, st); st.mod++; return; }
-    if (Freq[1] == 'N') { mod_smooth(a, start, end, Freq[0], newqs, lowQS, st); st.mod++; return; }
+    if (base_num < (u64)(long long)a.m) { st.disc++; return false; }                   // :520
+    if (Freq[0] == 'N') { mod_smooth(a, start, end, Freq[1], newqs, lowQS, st); st.mod++; return false; }
+    if (Freq[1] == 'N') { mod_smooth(a, start, end, Freq[0], newqs, lowQS, st); st.mod++; return false; }
 
     // :542-565 the symbols preceding the two frequent bases: bwt[LF(j)]
     u8 symbPrec[2] = {0, 0};
@@ -202,6 +211,7 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
     } else {
         st.amb++;
     }
+    return false;
 }
 
 // ---- one workgroup per chunk of rows: the chunk's cluster starts (rows r with in(r) && !in(r-1))
@@ -210,7 +220,6 @@ __device__ __forceinline__ void process_cluster_body(const ClusterArgs &a, u64 s
 // reference does.  A cluster belongs to the chunk it starts in; its rows may extend past the
 // chunk end.  Statistics (bfq_int.cpp:53-62) stay in per-thread scalars until the kernel ends.
 #define CL_CHUNK 4096
-#define CL_BIG 2048                                  // rows scanned by one thread before a cluster goes to k_cluster_big
 #define CL_WROWS (CL_CHUNK / 4)                       // rows per wave
 __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
 {
@@ -218,21 +227,28 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
     __shared__ u16 starts[4][CL_WROWS];               // per wave: chunk-local start rows
     __shared__ u32 wn[4];
     const u32 lane = bfq_lane(), w = threadIdx.x >> 6;
-    const u64 ltmask = bfq_lanemask_lt();
     if (threadIdx.x < 8) shst[threadIdx.x] = 0;
     ClStat st = {0, 0, 0, 0, 0, 0, 0, 0};
     for (u64 ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
-        u64 base = ch * CL_CHUNK + (u64)w * CL_WROWS;
-        u32 cntw = 0;
-#pragma unroll 2
-        for (int k = 0; k < CL_WROWS / 64; k++) {                  // wave order = row order
-            u32 li = k * 64 + lane;
-            u64 r = base + li;
-            bool s = r >= 1 && r < a.n && a.in[r] && !a.in[r - 1];
-            u64 m = __ballot(s);
-            if (s) starts[w][cntw + (u32)__popcll(m & ltmask)] = (u16)(w * CL_WROWS + li);
-            cntw += (u32)__popcll(m);
+        // 16 rows per lane: one 16-byte load of in() + the flag before them; lane order = row order
+        const u64 r0 = ch * CL_CHUNK + (u64)w * CL_WROWS + (u64)lane * (CL_WROWS / 64);
+        u32 bits = 0;                                              // bit k: in(r0 + k), rows past n are 0
+        if (r0 < a.n) {
+            uint4 x = *(const uint4 *)(a.in + r0);                 // in[] is padded by 64 bytes
+            u32 wds[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) bits |= ((wds[q] >> (8 * b)) & 1u) << (4 * q + b);
+            if (r0 + 16 > a.n) bits &= (1u << (u32)(a.n - r0)) - 1u;
         }
+        u32 prev = (r0 >= 1 && r0 < a.n) ? (u32)a.in[r0 - 1] & 1u : 0u;
+        u32 sb = bits & ~((bits << 1) | prev) & 0xFFFFu;           // cluster starts: in(r) && !in(r-1)
+        u32 ns = (u32)__popc(sb);
+        u32 incl = bfq_wave_incscan32(ns);
+        u32 o = incl - ns;
+        while (sb) { u32 k = (u32)__builtin_ctz(sb); starts[w][o++] = (u16)(w * CL_WROWS + lane * (CL_WROWS / 64) + k); sb &= sb - 1; }
+        u32 cntw = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         if (lane == 0) wn[w] = cntw;
         __syncthreads();
         u32 n0 = wn[0], n1 = wn[1], n2 = wn[2], n3 = wn[3];
@@ -241,19 +257,7 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
             u32 ww = t < n0 ? 0u : (t < n0 + n1 ? 1u : (t < n0 + n1 + n2 ? 2u : 3u));
             u32 idx = t - (ww == 0 ? 0u : (ww == 1 ? n0 : (ww == 2 ? n0 + n1 : n0 + n1 + n2)));
             u64 r = ch * CL_CHUNK + starts[ww][idx];
-            u64 e = r;
-            bool big = false;
-            for (;;) {                                              // in[] is padded: 8 flags per 8-byte load
-                u64 x = *(const u64 *)(a.in + e + 1);
-                u64 z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;   // first zero byte
-                u32 run = z ? (u32)(__builtin_ctzll(z) >> 3) : 8u;
-                if (e + run >= a.n) run = (u32)(a.n - 1 - e);
-                e += run;
-                if (run < 8 || e + 1 >= a.n) break;
-                if (e - r >= CL_BIG) { big = true; break; }
-            }
-            if (big) { a.bigStart[atomicAdd(&a.cnt->bigClusters, 1ull)] = r; continue; }
-            process_cluster_body(a, r - 1, e, st);
+            if (process_cluster_body(a, r - 1, st)) a.bigStart[atomicAdd(&a.cnt->bigClusters, 1ull)] = r;
         }
         __syncthreads();
     }
