@@ -29,6 +29,7 @@
 
 #define LCP_PENDING 0xFFFFu
 #define RF_CHUNK 2048                               // rows per wavefront chunk
+#define RF_HBW (RF_CHUNK / 64 + 4)                  // head-bit words per chunk: its rows + 256 rows of lookahead
 
 // payload <-> working form: word index (34 bits) | 3*offset (6 bits) << 34 | code << 40 | quality << 43 of p + 16
 __device__ __forceinline__ u64 wo_from_pay(u64 pay)
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                                                       u64 n, u64 *__restrict__ biglist, DevCounters *cnt, u64 nchunks)
 {
     // every wavefront works alone on its own chunk (no workgroup barriers): private LDS slices
-    __shared__ u64 hb_all[4][RF_CHUNK / 64 + 2];    // head bits of rows [base, base + RF_CHUNK + 128)
+    __shared__ u64 hb_all[4][RF_HBW];               // head bits of rows [base, base + RF_CHUNK + 256)
     __shared__ u32 segs_all[4][RF_CHUNK / 2];       // chunk-local start | size << 16  (size 0: longer than a wavefront)
     const u32 lane = bfq_lane(), w = threadIdx.x >> 6;
     u64 *hb = hb_all[w];
@@ -68,20 +69,41 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 ch = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; ch < nchunks; ch += nwaves) {
         const u64 base = ch * RF_CHUNK;
-        // 1. segment heads from the sorted keys (+ LCP of this chunk's head rows)
-#pragma unroll 2
-        for (u32 g = 0; g < RF_CHUNK / 64 + 2; g++) {
-            u64 r = base + (u64)g * 64 + lane;
-            bool h = true;                                     // rows past the end close the last segment
-            u64 k = (r < n) ? rec_key(rec, r) : 0ull;
-            u64 kp = bfq_from_prev_lane(k);                    // key of row r-1: the previous lane's, one extra load for lane 0
-            if (lane == 0 && r && r < n) kp = rec_key(rec, r - 1);
-            if (r < n) {
-                h = (r == 0) || seg_head(kp, k);
-                if (h && g < RF_CHUNK / 64) lcp[r] = r ? (u16)bfq_key48_lcp(kp, k) : (u16)0;
+        // 1. segment heads from the sorted keys (+ LCP of this chunk's head rows): 4 rows per lane and step
+        //    (16 B of w0, 32 B of w12), head bits OR-ed into LDS words in row order
+        for (u32 i = lane; i < RF_HBW; i += 64) hb[i] = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (u32 g = 0; g < RF_HBW / 4; g++) {
+            const u32 li0 = g * 256 + lane * 4;
+            const u64 r0 = base + li0;
+            u64 k[4];
+            if (li0 >= RF_CHUNK + 128) {                       // beyond the lookahead any segment search needs
+                k[0] = k[1] = k[2] = k[3] = 0ull;
+            } else if (r0 + 4 <= n) {
+                uint4 a = *(const uint4 *)(rec.w0 + r0);
+                uint4 b0 = *(const uint4 *)(rec.w12 + r0), b1 = *(const uint4 *)(rec.w12 + r0 + 2);
+                k[0] = bfq_rec_key48(a.x, b0.x); k[1] = bfq_rec_key48(a.y, b0.z);
+                k[2] = bfq_rec_key48(a.z, b1.x); k[3] = bfq_rec_key48(a.w, b1.z);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) k[i] = (r0 + i < n) ? rec_key(rec, r0 + i) : 0ull;
             }
-            u64 m = __ballot(h);
-            if (lane == 0) hb[g] = m;
+            u64 kp = bfq_from_prev_lane(k[3]);                 // key of row r0-1: the previous lane's last, one extra load for lane 0
+            if (lane == 0 && r0 && r0 - 1 < n) kp = rec_key(rec, r0 - 1);
+            u32 nib = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const u64 r = r0 + i;
+                bool h = true;                                 // rows past the end close the last segment
+                if (r < n) {
+                    h = (r == 0) || seg_head(kp, k[i]);
+                    if (h && li0 + i < RF_CHUNK) lcp[r] = r ? (u16)bfq_key48_lcp(kp, k[i]) : (u16)0;
+                }
+                nib |= (h ? 1u : 0u) << i;
+                kp = k[i];
+            }
+            atomicOr((unsigned long long *)&hb[g * 4 + (lane >> 4)], (unsigned long long)nib << (4 * (lane & 15)));
         }
         __builtin_amdgcn_wave_barrier();
         // 2. the chunk's segments of >= 2 rows, in row order, into LDS
