@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
     u64 *hb = hb_all[w];
     u32 *segs = segs_all[w];
     const u64 le = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const u64 ltmask = bfq_lanemask_lt();
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 ch = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; ch < nchunks; ch += nwaves) {
         const u64 base = ch * RF_CHUNK;
@@ -106,29 +105,31 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
             atomicOr((unsigned long long *)&hb[g * 4 + (lane >> 4)], (unsigned long long)nib << (4 * (lane & 15)));
         }
         __builtin_amdgcn_wave_barrier();
-        // 2. the chunk's segments of >= 2 rows, in row order, into LDS
-        u32 nsegs = 0;
-#pragma unroll 1
-        for (int k = 0; k < RF_CHUNK / 64; k++) {
-            u32 li = k * 64 + lane;
-            u64 r = base + li;
-            bool s = (r + 1 < n) && ((hb[li >> 6] >> (li & 63)) & 1ull) && !((hb[(li + 1) >> 6] >> ((li + 1) & 63)) & 1ull);
-            u32 size = 0;
-            if (s) {
-                u32 idx = li + 1;
-                u64 wd = hb[idx >> 6] >> (idx & 63);
+        // 2. the chunk's segments of >= 2 rows, in row order, into LDS: one head word (64 rows) per lane
+        u32 nsegs;
+        {
+            const bool on = lane < RF_CHUNK / 64;
+            const u64 hw = on ? hb[lane] : ~0ull, hn = on ? hb[lane + 1] : ~0ull;
+            u64 S = on ? (hw & ~((hw >> 1) | (hn << 63))) : 0ull;   // head followed by a non-head (rows past n are heads)
+            const u32 c = (u32)__popcll(S);
+            const u32 incl = bfq_wave_incscan32(c);
+            u32 o = incl - c;
+            while (S) {
+                const u32 li = lane * 64 + (u32)__builtin_ctzll(S);
+                S &= S - 1;
+                const u32 idx = li + 1;                            // first row that may be the next head
+                const u64 wd = hb[idx >> 6] >> (idx & 63);
                 u32 nxt;
                 if (wd) nxt = idx + (u32)__builtin_ctzll(wd);
                 else {
-                    u64 w2 = hb[(idx >> 6) + 1];
+                    const u64 w2 = hb[(idx >> 6) + 1];
                     nxt = w2 ? (((idx >> 6) + 1) << 6) + (u32)__builtin_ctzll(w2) : 0xFFFFu;
                 }
-                size = nxt - li;
-                if (size > 64) size = 0;                       // handled by k_refine_big
+                u32 size = nxt - li;
+                if (size > 64) size = 0;                           // handled by k_refine_big
+                segs[o++] = li | (size << 16);
             }
-            u64 sm = __ballot(s);
-            if (s) segs[nsegs + (u32)__popcll(sm & ltmask)] = li | (size << 16);
-            nsegs += (u32)__popcll(sm);
+            nsegs = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         }
         __builtin_amdgcn_wave_barrier();
         if (lane == 0 && nsegs) atomicAdd(&cnt->nSegs, (u64)nsegs);
