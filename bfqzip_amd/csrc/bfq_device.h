@@ -42,26 +42,40 @@ __device__ __forceinline__ u64 bfq_from_prev_lane(u64 v)   // lane i <- lane i-1
     return ((u64)hi << 32) | lo;
 }
 
-// inclusive wave scan (sum) of u64 / u32
-__device__ __forceinline__ u64 bfq_wave_incscan64(u64 v)
-{
-    u32 lane = bfq_lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u64 t = bfq_bpermute64(v, (int)lane - d);
-        if ((int)lane >= d) v += t;
-    }
-    return v;
-}
+// inclusive wave scan (sum) of u64 / u32: DPP row shifts inside each row of 16 lanes (VALU moves,
+// zero shifted in), then the totals of the rows before mine by three readlanes
+#define BFQ_DPP_ROW_SHR(v, k) __builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (k), 0xF, 0xF, true)
 __device__ __forceinline__ u32 bfq_wave_incscan32(u32 v)
 {
-    u32 lane = bfq_lane();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 t = (u32)__builtin_amdgcn_ds_bpermute(((int)lane - d) << 2, (int)v);
-        if ((int)lane >= d) v += t;
+    v += (u32)BFQ_DPP_ROW_SHR(v, 1);
+    v += (u32)BFQ_DPP_ROW_SHR(v, 2);
+    v += (u32)BFQ_DPP_ROW_SHR(v, 4);
+    v += (u32)BFQ_DPP_ROW_SHR(v, 8);
+    const u32 t0 = (u32)__builtin_amdgcn_readlane((int)v, 15), t1 = (u32)__builtin_amdgcn_readlane((int)v, 31),
+              t2 = (u32)__builtin_amdgcn_readlane((int)v, 47);
+    const u32 row = bfq_lane() >> 4;
+    return v + (row >= 1 ? t0 : 0u) + (row >= 2 ? t1 : 0u) + (row >= 3 ? t2 : 0u);
+}
+__device__ __forceinline__ u64 bfq_row_shr64(u64 v, int k)   // k in {1,2,4,8}: compile-time after inlining
+{
+    u32 lo, hi;
+    switch (k) {
+    case 1: lo = (u32)BFQ_DPP_ROW_SHR((u32)v, 1); hi = (u32)BFQ_DPP_ROW_SHR((u32)(v >> 32), 1); break;
+    case 2: lo = (u32)BFQ_DPP_ROW_SHR((u32)v, 2); hi = (u32)BFQ_DPP_ROW_SHR((u32)(v >> 32), 2); break;
+    case 4: lo = (u32)BFQ_DPP_ROW_SHR((u32)v, 4); hi = (u32)BFQ_DPP_ROW_SHR((u32)(v >> 32), 4); break;
+    default: lo = (u32)BFQ_DPP_ROW_SHR((u32)v, 8); hi = (u32)BFQ_DPP_ROW_SHR((u32)(v >> 32), 8); break;
     }
-    return v;
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 bfq_wave_incscan64(u64 v)
+{
+    v += bfq_row_shr64(v, 1);
+    v += bfq_row_shr64(v, 2);
+    v += bfq_row_shr64(v, 4);
+    v += bfq_row_shr64(v, 8);
+    const u64 t0 = bfq_readlane64(v, 15), t1 = bfq_readlane64(v, 31), t2 = bfq_readlane64(v, 47);
+    const u32 row = bfq_lane() >> 4;
+    return v + (row >= 1 ? t0 : 0ull) + (row >= 2 ? t1 : 0ull) + (row >= 3 ? t2 : 0ull);
 }
 
 // exclusive scan over a 256-thread workgroup; sh must hold 4 entries; returns the

@@ -77,6 +77,10 @@ __global__ __launch_bounds__(256) void k_lf_build(const u8 *__restrict__ bwt, co
         else for (u64 k = 0; r0 + k < n; k++) q4 |= (u32)qs[r0 + k] << (8 * k);
         u64 p = packed_counts(code);
         u64 ex = bfq_wave_incscan64(p) - p;         // packed counts of the rows before mine in the group
+        // F[c] + occurrences of c before this group: loaded by lanes 1..5, handed to everyone as wave-uniform values
+        u64 fg = (lane >= 1 && lane <= 5) ? scanned[(u64)lane * ngroups + g] : 0ull;
+        const u64 G1 = F[1] + bfq_readlane64(fg, 1), G2 = F[2] + bfq_readlane64(fg, 2), G3 = F[3] + bfq_readlane64(fg, 3),
+                  G4 = F[4] + bfq_readlane64(fg, 4), G5 = F[5] + bfq_readlane64(fg, 5);
         u64 outv[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -84,7 +88,7 @@ __global__ __launch_bounds__(256) void k_lf_build(const u8 *__restrict__ bwt, co
             u64 x = 0;
             if (c >= 1 && c <= 5) {
                 u32 before = (u32)(ex >> (10 * c)) & 0x3FFu;
-                x = (c == 1 ? F[1] : c == 2 ? F[2] : c == 3 ? F[3] : c == 4 ? F[4] : F[5]) + scanned[(u64)c * ngroups + g] + before;
+                x = (c == 1 ? G1 : c == 2 ? G2 : c == 3 ? G3 : c == 4 ? G4 : G5) + before;
             }
             if (c < 6) ex += 1ull << (10 * c);
             outv[k] = x | ((u64)(c & 7u) << 40) | ((u64)((q4 >> (8 * k)) & 0xFFu) << 48);
