@@ -78,6 +78,19 @@ __device__ __forceinline__ u64 bfq_wave_incscan64(u64 v)
     return v + (row >= 1 ? t0 : 0ull) + (row >= 2 ? t1 : 0ull) + (row >= 3 ? t2 : 0ull);
 }
 
+// the same through the LDS crossbar (ds_bpermute): fewer live registers than the DPP sequence, for
+// kernels at their VGPR limit (k_radix_scatter)
+__device__ __forceinline__ u32 bfq_wave_incscan32_bp(u32 v)
+{
+    u32 lane = bfq_lane();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = (u32)__builtin_amdgcn_ds_bpermute(((int)lane - d) << 2, (int)v);
+        if ((int)lane >= d) v += t;
+    }
+    return v;
+}
+
 // exclusive scan over a 256-thread workgroup; sh must hold 4 entries; returns the
 // exclusive prefix, *total = workgroup sum.  Contains two __syncthreads().
 __device__ __forceinline__ u64 bfq_block_exscan64(u64 v, u64 *sh, u64 *total)

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
             for (int k = 0; k < RS_WAVES; k++) { u32 ck = wcnt[k][tid]; wcnt[k][tid] = tot; tot += ck; }
         }
         {                                                        // exclusive scan of tot over the workgroup
-            u32 inc = bfq_wave_incscan32(tot);
+            u32 inc = bfq_wave_incscan32_bp(tot);
             if (lane == 63) shscan[w] = inc;
             __syncthreads();
             u32 base = 0;

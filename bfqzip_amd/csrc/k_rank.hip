@@ -48,8 +48,7 @@ __global__ __launch_bounds__(256) void k_lf_count(const u8 *__restrict__ bwt, u6
         u32 code[4];
         codes4(bwt, g * 256 + (u64)lane * 4, n, term, code, &bad);
         u64 p = packed_counts(code);
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) p += bfq_bpermute64(p, (int)(lane ^ d));      // wave total in every lane
+        p = bfq_readlane64(bfq_wave_incscan64(p), 63);                                  // wave total in every lane
         if (lane < 6) gcnt[(u64)lane * ngroups + g] = (u32)(p >> (10 * lane)) & 0x3FFu;
     }
     if (bad) atomicAdd(&cnt->errSymbol, 1ull);

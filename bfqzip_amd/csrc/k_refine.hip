@@ -321,11 +321,18 @@ __global__ __launch_bounds__(256) void k_emit_bwt(SortRec rec, u64 n, u32 termOu
         const u64 r0 = g * 256 + (u64)lane * 4;
         u32 b4 = 0, q4 = 0;
         u64 p = 0;
+        u64 x[4] = {0, 0, 0, 0};
+        if (r0 + 4 <= n) {
+            uint4 a = *(const uint4 *)(rec.w12 + r0), b = *(const uint4 *)(rec.w12 + r0 + 2);
+            x[0] = ((u64)a.y << 32) | a.x; x[1] = ((u64)a.w << 32) | a.z;
+            x[2] = ((u64)b.y << 32) | b.x; x[3] = ((u64)b.w << 32) | b.z;
+        } else {
+            for (u64 k = 0; r0 + k < n; k++) x[k] = rec.w12[r0 + k];
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             if (r0 + k < n) {
-                u64 x = rec.w12[r0 + k];
-                u64 v = bfq_rec_pay((u32)x, (u32)(x >> 32));
+                u64 v = bfq_rec_pay((u32)x[k], (u32)(x[k] >> 32));
                 u32 code = bfq_val_code(v);
                 b4 |= (u32)(code ? bfq_code_sym(code) : (u8)termOut) << (8 * k);
                 q4 |= bfq_val_qual(v) << (8 * k);
@@ -334,8 +341,7 @@ __global__ __launch_bounds__(256) void k_emit_bwt(SortRec rec, u64 n, u32 termOu
         }
         if (r0 + 4 <= n) { *(u32 *)(bwt + r0) = b4; *(u32 *)(qs + r0) = q4; }
         else for (u64 k = 0; r0 + k < n; k++) { bwt[r0 + k] = (u8)(b4 >> (8 * k)); qs[r0 + k] = (u8)(q4 >> (8 * k)); }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) p += bfq_bpermute64(p, (int)(lane ^ d));
+        p = bfq_readlane64(bfq_wave_incscan64(p), 63);         // the group's packed symbol counts
         if (lane < 6) gcnt[(u64)lane * ngroups + g] = (u32)(p >> (10 * lane)) & 0x3FFu;
     }
 }
