@@ -37,19 +37,21 @@ __global__ __launch_bounds__(256) void k_text_from_reads(const u8 *__restrict__ 
         u64 b = roff[i], e = roff[i + 1];
         u64 t0 = b + i, len = e - b;
         if (len > BFQ_MAX_READ_LEN) tooLong = true;
-        for (u64 k = (u64)sub * 8; k < len; k += 128) {
-            if (k + 8 <= len) {
+        if (len >= 8) {                                           // the last word overlaps the one before: no byte tail
+            const u64 nw = (len + 7) >> 3;
+            for (u64 j = sub; j < nw; j += 16) {
+                const u64 k = (8 * j + 8 <= len) ? 8 * j : len - 8;
                 u64 xb = *(const u64 *)(bases + b + k);
                 u64 xq = *(const u64 *)(quals + b + k);
                 *(u64 *)(T8 + t0 + k) = codes8(xb, &bad);
                 *(u64 *)(Q8 + t0 + k) = xq;
-            } else {
-                for (u64 j = k; j < len; j++) {
-                    u32 code = bfq_base_code(bases[b + j]);
-                    if (code == BFQ_CODE_INVALID) { bad = true; code = 4; }
-                    T8[t0 + j] = (u8)code;
-                    Q8[t0 + j] = quals[b + j];
-                }
+            }
+        } else if (sub == 0) {
+            for (u64 j = 0; j < len; j++) {
+                u32 code = bfq_base_code(bases[b + j]);
+                if (code == BFQ_CODE_INVALID) { bad = true; code = 4; }
+                T8[t0 + j] = (u8)code;
+                Q8[t0 + j] = quals[b + j];
             }
         }
         if (sub == 0) { T8[t0 + len] = 0; Q8[t0 + len] = (u8)'#'; }
@@ -64,11 +66,17 @@ __global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n,
     for (u64 w = (u64)blockIdx.x * blockDim.x + threadIdx.x; w < nwords; w += (u64)gridDim.x * blockDim.x) {
         u64 p0 = w * BFQ_SYMS_PER_WORD;
         u64 v = 0;
+        if (p0 + 24 <= n) {                                       // three unaligned 8-byte loads cover the 21 codes
+            u64 x[3] = {*(const u64 *)(T8 + p0), *(const u64 *)(T8 + p0 + 8), *(const u64 *)(T8 + p0 + 16)};
 #pragma unroll
-        for (int j = 0; j < BFQ_SYMS_PER_WORD; j++) {
-            u64 p = p0 + j;
-            u64 c = (p < n) ? (u64)T8[p] : 0ull;
-            v = (v << 3) | c;
+            for (int j = 0; j < BFQ_SYMS_PER_WORD; j++) v = (v << 3) | ((x[j >> 3] >> (8 * (j & 7))) & 7ull);
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < BFQ_SYMS_PER_WORD; j++) {
+                u64 p = p0 + j;
+                u64 c = (p < n) ? (u64)T8[p] : 0ull;
+                v = (v << 3) | c;
+            }
         }
         text3[w] = v;
     }
