@@ -281,7 +281,6 @@ static void steps234_device(bfq_ctx *c, const u64 *d_roff, u8 *d_out_bases, u8 *
 {
     u64 n = c->n, N = c->N;
     if (!n) return;
-    if ((((uintptr_t)d_out_bases) | ((uintptr_t)d_out_quals)) & 15) throw BfqError{BFQ_E_ARG, "output buffers must be 16-byte aligned"};
     // the symbol counts of step 1's emission are reused when this eBWT is the one it just wrote
     const u32 *gc = (c->d_gcnt && c->gcntTerm == (c->P.term & 0xFF)) ? c->d_gcnt : nullptr;
     RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term, gc);

@@ -6,7 +6,7 @@
 // -- Illumina-binned when B=1, bfq_int.cpp:784-786) and moves to LF(row) until
 // the terminator row.  One step = ONE 8-byte read of the LF table (bfq_rank.h);
 // N walks in flight hide the dependent-load latency; output bytes are collected in
-// registers and stored 16 at a time.
+// registers and stored 16 at a time (chunks counted from the end of the read).
 #include <stdlib.h>
 #include "bfq_internal.h"
 #include "bfq_device.h"
@@ -28,15 +28,17 @@ __global__ __launch_bounds__(256) void k_invert_count(RankIndex R, u64 N, u32 *_
     }
 }
 
-// bytes [from,to) of the 16-byte chunk at from & ~15 (lo = bytes 0..7, hi = bytes 8..15)
-__device__ __forceinline__ void flush_bytes(u8 *dst, u64 from, u64 to, u64 lo, u64 hi)
+// the low `cnt` (< 8) bytes of v to dst, as 4 + 2 + 1 byte stores (unaligned stores are exact on gfx950)
+__device__ __forceinline__ void store_tail(u8 *dst, u64 v, u32 cnt)
 {
-    for (u64 p = from; p < to; p++) {
-        u32 o = (u32)p & 15u;
-        dst[p] = (u8)((o < 8 ? lo : hi) >> (8 * (o & 7u)));
-    }
+    if (cnt & 4u) { *(u32 *)dst = (u32)v; v >>= 32; dst += 4; }
+    if (cnt & 2u) { *(u16 *)dst = (u16)v; v >>= 16; dst += 2; }
+    if (cnt & 1u) *dst = (u8)v;
 }
 
+// The walk produces a read back to front.  Output bytes are collected in chunks of 16 counted from the
+// read's END ([end-16, end), [end-32, end-16), ...), each stored as two unaligned 8-byte words, so only the
+// front of the read (len mod 16 bytes) needs narrower stores.
 template <int NT>
 __global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *__restrict__ roff, int B,
                                                 u8 *__restrict__ out_bases, u8 *__restrict__ out_quals, DevCounters *cnt)
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *_
         const u64 lo = roff[i], end = roff[i + 1];
         u64 pos = end, j = i;
         u64 bl = 0, bh = 0, ql = 0, qh = 0;                            // 16 output bytes of each stream
+        u32 have = 0;                                                  // bytes in the current chunk (filled from the top)
         bool bad = false;
         while (pos > lo) {
             u64 x = NT ? __builtin_nontemporal_load(R.lfq + j) : R.lfq[j];
@@ -55,26 +58,28 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *_
             u32 q = lfq_qual(x);
             if (B) q = bfq_bin8(q);
             --pos;
-            u32 o = (u32)pos & 15u, sh = (o & 7u) * 8u;
+            u32 o = 15u - have, sh = (o & 7u) * 8u;
             if (o < 8) { bl |= (u64)sym << sh; ql |= (u64)q << sh; }
             else { bh |= (u64)sym << sh; qh |= (u64)q << sh; }
-            if (o == 0) {                                            // chunk [pos,pos+16) is complete or clipped by `end`
-                if (pos + 16 <= end) {
-                    *(ulonglong2 *)(out_bases + pos) = make_ulonglong2(bl, bh);
-                    *(ulonglong2 *)(out_quals + pos) = make_ulonglong2(ql, qh);
-                } else {
-                    flush_bytes(out_bases, pos, end, bl, bh);
-                    flush_bytes(out_quals, pos, end, ql, qh);
-                }
+            if (++have == 16) {                                      // chunk [pos, pos+16) complete
+                *(u64 *)(out_bases + pos) = bl; *(u64 *)(out_bases + pos + 8) = bh;
+                *(u64 *)(out_quals + pos) = ql; *(u64 *)(out_quals + pos + 8) = qh;
                 bl = bh = ql = qh = 0;
+                have = 0;
             }
             j = nx;
         }
-        if (!bad && (lo & 15)) {                                     // leading partial chunk [lo, min(end, align_up(lo)))
-            u64 hi = (lo + 15) & ~15ull;
-            if (hi > end) hi = end;
-            flush_bytes(out_bases, lo, hi, bl, bh);
-            flush_bytes(out_quals, lo, hi, ql, qh);
+        if (!bad && have) {                                          // front of the read: `have` bytes at the top of the chunk
+            const u32 s = 16u - have;                                // bytes to shift out (1..15)
+            u64 b0, b1, q0, q1;
+            if (s >= 8) { b0 = bh >> (8 * (s - 8)); q0 = qh >> (8 * (s - 8)); b1 = q1 = 0; }
+            else { b0 = (bl >> (8 * s)) | (bh << (64 - 8 * s)); q0 = (ql >> (8 * s)) | (qh << (64 - 8 * s)); b1 = bh >> (8 * s); q1 = qh >> (8 * s); }
+            if (have >= 8) {
+                *(u64 *)(out_bases + lo) = b0; *(u64 *)(out_quals + lo) = q0;
+                store_tail(out_bases + lo + 8, b1, have - 8); store_tail(out_quals + lo + 8, q1, have - 8);
+            } else {
+                store_tail(out_bases + lo, b0, have); store_tail(out_quals + lo, q0, have);
+            }
         }
         if (!bad && lfq_code(R.lfq[j]) != 0) bad = true;             // read longer than its slot
         if (bad) atomicAdd(&cnt->errInvert, 1ull);
