@@ -55,6 +55,19 @@ __device__ __forceinline__ u64 wo_key(const u64 *__restrict__ text3, u64 v, u32 
     return bfq_mask_key(hi | lo);
 }
 
+// the two consecutive masked windows `round` and `round + 1` words along the suffix (three text words);
+// the second one is 0 when the first already holds the terminator
+__device__ __forceinline__ void wo_key2(const u64 *__restrict__ text3, u64 v, u32 round, u64 &W1, u64 &W2)
+{
+    u64 w = (v & ((1ull << 34) - 1ull)) + round;
+    u32 o = (u32)(v >> 34) & 63u;
+    u64 t0 = text3[w], t1 = text3[w + 1], t2 = text3[w + 2];
+    u64 a = (t0 << o) & BFQ_M63, b = (t1 << o) & BFQ_M63;
+    if (o) { a |= t1 >> (63u - o); b |= t2 >> (63u - o); }
+    W1 = bfq_mask_key(a);
+    W2 = bfq_key_has_term(W1) ? 0ull : bfq_mask_key(b);
+}
+
 __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restrict__ lcp, const u64 *__restrict__ text3,
                                                       u64 n, u64 *__restrict__ biglist, DevCounters *cnt, u64 nchunks)
 {
@@ -170,21 +183,23 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                 curHeads = __ballot(!act || (int)lane == sublo);
                 u32 depth = BFQ_KEY_SYMS;
                 u32 round = 0;
-                while (unres) {
+                while (unres) {                                                     // one round = the next 42 symbols
                     const bool un = (unres >> lane) & 1ull;
-                    u64 W = un ? wo_key(text3, v, round) : 0ull;
+                    u64 W1 = 0, W2 = 0;
+                    if (un) wo_key2(text3, v, round, W1, W2);
                     // longest open sub-segment = longest run of non-head lanes + 1 (scalar bit trick on the head mask)
                     u32 maxsz = 1;
                     for (u64 run = ~curHeads; run; run &= run >> 1) maxsz++;
-                    // stable rank of a row inside its sub-segment = #(later rows with a smaller word)
-                    // + #(earlier rows with a word <= its own).  Only the first kind is compared
-                    // (W of lane+d arrives by a one-lane DPP shift per step); the ballot of those
+                    // stable rank of a row inside its sub-segment = #(later rows with a smaller word pair)
+                    // + #(earlier rows with a pair <= its own).  Only the first kind is compared
+                    // (the pair of lane+d arrives by one-lane DPP shifts per step); the ballot of those
                     // comparisons, read at lane-d, gives the second kind by complement.
                     int c = 0, inv = 0;
-                    u64 Wu = W;
+                    u64 U1 = W1, U2 = W2;
                     for (u32 d = 1; d < maxsz; d++) {
-                        Wu = bfq_from_next_lane(Wu);
-                        bool f = un && ((int)lane + (int)d < subhi) && (Wu < W);     // row lane+d sorts before me
+                        U1 = bfq_from_next_lane(U1);
+                        U2 = bfq_from_next_lane(U2);
+                        bool f = un && ((int)lane + (int)d < subhi) && (U1 < W1 || (U1 == W1 && U2 < W2));   // row lane+d sorts before me
                         u64 fb = __ballot(f);
                         c += f ? 1 : 0;
                         if (lane >= d) inv += (int)((fb >> (lane - d)) & 1ull);      // I sort before row lane-d
@@ -192,18 +207,21 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                     c += ((int)lane - sublo) - inv;
                     int np = un ? sublo + c : (int)lane;
                     v = bfq_permute64(v, np);
-                    W = bfq_permute64(W, np);
-                    u64 Wprev = bfq_from_prev_lane(W);
-                    bool newhead = un && ((int)lane == sublo || W != Wprev || bfq_key_has_term(W));
-                    if (un && (int)lane != sublo && newhead) mylcp = depth + (u32)bfq_key_lcp(Wprev, W);
+                    W1 = bfq_permute64(W1, np);
+                    W2 = bfq_permute64(W2, np);
+                    const u64 P1 = bfq_from_prev_lane(W1), P2 = bfq_from_prev_lane(W2);
+                    const bool d1 = (W1 != P1) || bfq_key_has_term(W1);             // decided by the first word
+                    bool newhead = un && ((int)lane == sublo || d1 || W2 != P2 || bfq_key_has_term(W2));
+                    if (un && (int)lane != sublo && newhead)
+                        mylcp = d1 ? depth + (u32)bfq_key_lcp(P1, W1) : depth + BFQ_SYMS_PER_WORD + (u32)bfq_key_lcp(P2, W2);
                     u64 heads = __ballot(newhead || !un);
                     curHeads = heads;
                     sublo = 63 - __clzll((long long)(heads & le));
                     u64 above = heads & ~le;
                     subhi = above ? __builtin_ctzll(above) : 64;
                     unres = __ballot(un && (subhi - sublo > 1));
-                    depth += BFQ_SYMS_PER_WORD;
-                    round++;
+                    depth += 2 * BFQ_SYMS_PER_WORD;
+                    round += 2;
                 }
                 if (act) {
                     rec_set_pay(rec, myRow, wo_to_pay(v));
