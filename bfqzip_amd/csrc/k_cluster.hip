@@ -11,10 +11,10 @@
 //                 are disjoint, so each one is handled independently by the thread
 //                 that sits on its first in() row, walking it in row order exactly as
 //                 the reference does (the M=1 double sum keeps its order).
-//   k_cluster_big : clusters longer than CL_BIG rows (low-complexity reads: one cluster can span
-//                 millions of rows) get a whole workgroup: parallel counts, one decision,
-//                 parallel edits.  Same results; only the M=1 double sum stays sequential,
-//                 because its rounding depends on the order.
+//   k_big_*     : clusters longer than CL_BIG rows (low-complexity reads: one cluster can span
+//                 millions of rows) are cut into tiles spread over the whole device: counts by
+//                 atomics into a per-cluster state, one decision, edits tile by tile.  Same
+//                 results; only the M=1 double sum stays sequential (its rounding depends on the order).
 // Base replacements are recorded in modsym[r] (0 = untouched) instead of the
 // reference's rankbv bit + BWT_MOD string (bfq_int.cpp:386-387,582-591).
 #include <stdlib.h>
@@ -54,6 +54,7 @@ __global__ __launch_bounds__(256) void k_lcp_flags(const u16 *__restrict__ lcp, 
 
 struct ClStat { u32 clust, disc, amb, mod, alleq, bases, qs, modb; };
 
+struct BigState;
 struct ClusterArgs {
     RankIndex R;
     const u8 *bwt; const u8 *qual; const u8 *in; u64 n;
@@ -62,7 +63,8 @@ struct ClusterArgs {
     const double *qthr;     // [qthrN] decreasing: smallest x with round(-10*log10(x)) <= qthrLo+k
     int qthrLo, qthrN;
     DevCounters *cnt;
-    u64 *bigStart;          // first in() rows of the clusters left to k_cluster_big
+    u64 *bigStart;          // first in() rows of the clusters left to the k_big_* kernels
+    struct BigState *big;   // their state
 };
 
 __device__ __forceinline__ int ord5(u8 c)   // bfq_int.cpp:106-110: A0 C1 G2 T3 N4
@@ -104,7 +106,7 @@ __device__ __forceinline__ void mod_smooth(const ClusterArgs &a, u64 start, u64 
 
 // One cluster starting at row `start` (= first in() row - 1).  Its extent comes out of the same walk that
 // counts it: row j > start belongs while in[start+1..j] are all set.  Returns true (nothing done) when the
-// cluster outgrows CL_BIG rows: those go to k_cluster_big.
+// cluster outgrows CL_BIG rows: those go to the k_big_* kernels.
 #define CL_BIG 2048
 __device__ __forceinline__ bool process_cluster_body(const ClusterArgs &a, u64 start, ClStat &st)
 {
@@ -273,166 +275,219 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
     if (threadIdx.x < 8 && shst[threadIdx.x]) atomicAdd(&a.cnt->stats[threadIdx.x], (u64)shst[threadIdx.x]);
 }
 
-// ---- clusters longer than CL_BIG rows: one workgroup each ------------------------------------
-struct BigShared {
-    u64 freq[5], base;
+// ---- clusters longer than CL_BIG rows: tiles of CB_TILE rows spread over the whole device ------------
+// Per cluster one BigState in global memory: extent, counters (atomics from the tiles), the decision.
+//   k_big_extent : one workgroup per cluster finds its end (16 in() flags per thread and step)
+//   k_big_count  : tiles -> symbol frequencies, trusted-quality mask, quality sum / max          (:437-449)
+//   k_big_decide : one thread per cluster, the decision of :451-540 (M=1: the double sum, in row order)
+//   k_big_prec   : clusters with two frequent bases: the symbols that precede them               (:542-565)
+//   k_big_apply  : tiles -> edits                                                               (:376-405, :568-591)
+// Tile t of cluster i goes to workgroup (t + i) mod grid, so that many medium clusters and one huge
+// cluster both use every workgroup.
+struct BigState {
+    u64 start, end;           // rows [start, end]
+    u64 freq[5];
     u32 low, sum, mx, fr0, fr1;
-    int mode, newqs;          // mode 0 nothing, 1 mod_smooth towards sym0, 2 two frequent symbols
-    u8 sym0, sym1, prec0, prec1;
-    u64 end;
+    int mode, newqs;          // mode 0 nothing, 1 mod_smooth towards sym0, 2 two frequent bases (undecided), 3 the same, confirmed
+    u32 sym0, sym1;
 };
+#define CB_TILE 65536
+#define CB_GRID 2048
 
-__device__ void big_cluster(const ClusterArgs &a, u64 start, u64 end, BigShared &sh)
-{
-    const u8 TERM = (u8)a.term;
-    const u32 tid = threadIdx.x;
-    if (tid == 0) {
-        for (int s = 0; s < 5; s++) sh.freq[s] = 0;
-        sh.base = 0; sh.low = 0; sh.sum = 0; sh.mx = 0; sh.fr0 = 0; sh.fr1 = 0; sh.mode = 0;
+// rows [ts, te] of one tile, 16 per thread and step: one 16-byte load each of the eBWT and of the qualities
+// (both 16-byte aligned and padded past n)
+#define CB_FOR_ROWS(...)                                                                               \
+    for (u64 g0 = (ts & ~15ull) + (u64)threadIdx.x * 16; g0 <= te; g0 += 256 * 16) {                  \
+        const uint4 xb4 = *(const uint4 *)(a.bwt + g0), xq4 = *(const uint4 *)(a.qual + g0);          \
+        const u32 xbw[4] = {xb4.x, xb4.y, xb4.z, xb4.w}, xqw[4] = {xq4.x, xq4.y, xq4.z, xq4.w};        \
+        _Pragma("unroll") for (int k = 0; k < 16; k++) {                                              \
+            const u64 j = g0 + k;                                                                      \
+            if (j < ts || j > te) continue;                                                            \
+            const u8 b = (u8)(xbw[k >> 2] >> (8 * (k & 3)));                                           \
+            const u8 qb = (u8)(xqw[k >> 2] >> (8 * (k & 3)));                                          \
+            (void)qb;                                                                                  \
+            __VA_ARGS__                                                                                       \
+        }                                                                                              \
     }
-    __syncthreads();
-    {                                                                          // :437-449 counts
-        u32 fA = 0, fC = 0, fG = 0, fT = 0, fN = 0, low = 0, sum = 0;
-        int mx = 0;
-        for (u64 j = start + tid; j <= end; j += 256) {
-            u8 b = a.bwt[j];
-            if (b == TERM) continue;
-            int q = (int)(signed char)a.qual[j];
-            int o = ord5(b);
-            fA += (o == 0); fC += (o == 1); fG += (o == 2); fT += (o == 3); fN += (o == 4);
-            if (q >= a.t + 33) low |= 1u << o;
-            sum += (u32)q;                                                     // wraps like the reference's int
-            if (q > mx) mx = q;
-        }
-        if (fA) atomicAdd(&sh.freq[0], (u64)fA);
-        if (fC) atomicAdd(&sh.freq[1], (u64)fC);
-        if (fG) atomicAdd(&sh.freq[2], (u64)fG);
-        if (fT) atomicAdd(&sh.freq[3], (u64)fT);
-        if (fN) atomicAdd(&sh.freq[4], (u64)fN);
-        if (low) atomicOr(&sh.low, low);
-        atomicAdd(&sh.sum, sum);
-        atomicMax(&sh.mx, (u32)mx);
+// the tiles of all big clusters that fall to this workgroup; `body` sees BigState &S, tile rows [ts, te]
+#define CB_FOR_TILES(...)                                                                              \
+    {                                                                                                  \
+        const u64 nbig = a.cnt->bigClusters;                                                           \
+        for (u64 bi = 0; bi < nbig; bi++) {                                                            \
+            BigState &S = a.big[bi];                                                                   \
+            const u64 ntiles = (S.end - S.start) / CB_TILE + 1;                                        \
+            for (u64 t = (blockIdx.x + gridDim.x - (u32)(bi % gridDim.x)) % gridDim.x; t < ntiles; t += gridDim.x) { \
+                const u64 ts = S.start + t * CB_TILE;                                                  \
+                const u64 te = (ts + CB_TILE - 1 < S.end) ? ts + CB_TILE - 1 : S.end;                  \
+                __VA_ARGS__                                                                                   \
+            }                                                                                          \
+        }                                                                                              \
     }
-    __syncthreads();
-    if (tid == 0) {                                                            // the decision of :451-580
-        u64 size = end - start + 1;
-        u64 base_num = sh.freq[0] + sh.freq[1] + sh.freq[2] + sh.freq[3] + sh.freq[4];
-        sh.base = base_num;
-        if (size >= (u64)(long long)a.m) {
-            atomicAdd(&a.cnt->stats[0], 1ull);
-            if (base_num) {
-                atomicAdd(&a.cnt->stats[5], base_num);
-                int newqs;
-                if (a.M == 1) {
-                    double sum_err = 0;
-                    for (u64 j = start; j <= end; j++)
-                        if (a.bwt[j] != TERM) sum_err = sum_err + a.powtab[a.qual[j]];
-                    double avg_err = sum_err / (double)base_num;
-                    int lo = 0, hi = a.qthrN - 1;
-                    while (lo < hi) { int mid = (lo + hi) >> 1; if (a.qthr[mid] <= avg_err) hi = mid; else lo = mid + 1; }
-                    int q = a.qthrLo + lo;
-                    newqs = a.ext ? (int)(signed char)(u8)((u8)q + 33) : (int)(signed char)(q + 33);
-                } else if (a.M == 2) {
-                    newqs = (int)(signed char)a.v;
-                } else if (a.M == 3) {
-                    int sum = (int)sh.sum;
-                    if (sum == 0) newqs = 0;
-                    else if (a.ext) newqs = (int)(signed char)(u8)roundf((float)sum / (float)base_num);
-                    else newqs = (int)(signed char)(int)((u64)(long long)sum / base_num);
-                } else {
-                    newqs = (int)sh.mx;
-                }
-                sh.newqs = newqs;
-                u8 Freq[5];
-                int nf = 0, nnn = 0;
-                for (int s = 0; s < 5; s++)
-                    if (sh.freq[s] > 0) {
-                        nnn++;
-                        u32 perc = (u32)((100ull * sh.freq[s]) / base_num) & 0xFFu;
-                        if ((float)perc >= (float)a.f) Freq[nf++] = dna5(s);
-                    }
-                if (nnn == 1) atomicAdd(&a.cnt->stats[4], 1ull);
-                if (nf >= 3) atomicAdd(&a.cnt->errFreq3, 1ull);
-                else if (nf == 0) atomicAdd(&a.cnt->stats[1], 1ull);
-                else if (nf == 1) {
-                    if (Freq[0] == 'N') atomicAdd(&a.cnt->stats[1], 1ull);
-                    else { sh.mode = 1; sh.sym0 = Freq[0]; }
-                } else if (base_num < (u64)(long long)a.m) atomicAdd(&a.cnt->stats[1], 1ull);
-                else if (Freq[0] == 'N') { sh.mode = 1; sh.sym0 = Freq[1]; atomicAdd(&a.cnt->stats[3], 1ull); }
-                else if (Freq[1] == 'N') { sh.mode = 1; sh.sym0 = Freq[0]; atomicAdd(&a.cnt->stats[3], 1ull); }
-                else { sh.mode = 2; sh.sym0 = Freq[0]; sh.sym1 = Freq[1]; }
-            }
-        }
-    }
-    __syncthreads();
-    const int mode = sh.mode, newqs = sh.newqs;
-    const u32 lowQS = sh.low;
-    const u8 s0 = sh.sym0, s1 = sh.sym1;
-    u32 modb = 0, qs = 0;
-    if (mode == 1) {                                                           // :376-405
-        for (u64 j = start + tid; j <= end; j += 256) {
-            u8 b = a.bwt[j];
-            if (b == TERM) continue;
-            if (b != s0 && !((lowQS >> ord5(b)) & 1u)) { set_mod(a, j, s0); modb++; }
-            else if (b == s0) { set_qual(a, j, newqs); qs++; }
-            else if (newqs < (int)(signed char)a.qual[j]) { set_qual(a, j, newqs); qs++; }
-        }
-    } else if (mode == 2) {                                                    // :542-591
-        u32 f0 = 0, f1 = 0;
-        for (u64 j = start + tid; j <= end; j += 256) {
-            u8 b = a.bwt[j];
-            if (b != s0 && b != s1) continue;
-            u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
-            if (ch != TERM && ch != 'N') { if (b == s0) f0 |= 1u << ord5(ch); else f1 |= 1u << ord5(ch); }
-        }
-        if (f0) atomicOr(&sh.fr0, f0);
-        if (f1) atomicOr(&sh.fr1, f1);
-        __syncthreads();
-        f0 = sh.fr0 & 15u; f1 = sh.fr1 & 15u;
-        // with exactly one preceding symbol per frequent base, "the last one seen" is that symbol
-        if (__popc(f0) == 1 && __popc(f1) == 1 && f0 != f1) {
-            const u8 p0 = dna5(__ffs(f0) - 1), p1 = dna5(__ffs(f1) - 1);
-            if (tid == 0) atomicAdd(&a.cnt->stats[3], 1ull);
-            for (u64 j = start + tid; j <= end; j += 256) {
-                u8 b = a.bwt[j];
-                if (b == TERM) continue;
-                if (b != s0 && b != s1 && !((lowQS >> ord5(b)) & 1u)) {
-                    u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
-                    if (ch == p0) { set_mod(a, j, s0); modb++; }
-                    else if (ch == p1) { set_mod(a, j, s1); modb++; }
-                } else if (b == s0 || b == s1) { set_qual(a, j, newqs); qs++; }
-                else if (newqs < (int)(signed char)a.qual[j]) { set_qual(a, j, newqs); qs++; }
-            }
-        } else if (tid == 0) atomicAdd(&a.cnt->stats[2], 1ull);
-    }
-    if (qs) atomicAdd(&a.cnt->stats[6], (u64)qs);
-    if (modb) atomicAdd(&a.cnt->stats[7], (u64)modb);
-}
 
-__global__ __launch_bounds__(256) void k_cluster_big(ClusterArgs a)
+__global__ __launch_bounds__(256) void k_big_extent(ClusterArgs a)
 {
-    __shared__ BigShared sh;
+    __shared__ u64 shEnd;
     const u64 nbig = a.cnt->bigClusters;
     for (u64 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         const u64 r = a.bigStart[bi];                               // cluster = [r-1, e], e = last row of the in() run
         __syncthreads();
-        if (threadIdx.x == 0) sh.end = ~0ull;
+        if (threadIdx.x == 0) shEnd = ~0ull;
         __syncthreads();
-        for (u64 b0 = r + 1;; b0 += 256 * 8) {
-            u64 i = b0 + (u64)threadIdx.x * 8;
-            u64 found = ~0ull;
-            for (u32 k = 0; k < 8; k++) {
-                u64 x = i + k;
-                if (x >= a.n || !a.in[x]) { found = x; break; }
+        for (u64 b0 = (r + 1) & ~15ull;; b0 += 256 * 16) {           // 16 flags per thread and step (in[] is padded)
+            const u64 i0 = b0 + (u64)threadIdx.x * 16;
+            if (i0 < a.n + 16) {
+                const uint4 x = *(const uint4 *)(a.in + i0);
+                const u32 wds[4] = {x.x, x.y, x.z, x.w};
+                for (u32 k = 0; k < 16; k++) {
+                    const u64 xr = i0 + k;
+                    if (xr <= r) continue;
+                    if (xr >= a.n || !((wds[k >> 2] >> (8 * (k & 3))) & 1u)) { atomicMin(&shEnd, xr); break; }
+                }
             }
-            if (found != ~0ull) atomicMin(&sh.end, found);
             __syncthreads();
-            bool done = (sh.end != ~0ull);
+            bool done = (shEnd != ~0ull);
             __syncthreads();
             if (done) break;
         }
-        big_cluster(a, r - 1, sh.end - 1, sh);
+        if (threadIdx.x == 0) {
+            BigState z = {};
+            z.start = r - 1; z.end = shEnd - 1;
+            a.big[bi] = z;
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void k_big_count(ClusterArgs a)
+{
+    const u8 TERM = (u8)a.term;
+    CB_FOR_TILES(
+        u32 fA = 0, fC = 0, fG = 0, fT = 0, fN = 0, low = 0, sum = 0;
+        int mx = 0;
+        CB_FOR_ROWS(
+            if (b != TERM) {
+                const int q = (int)(signed char)qb;
+                const int o = ord5(b);
+                fA += (o == 0); fC += (o == 1); fG += (o == 2); fT += (o == 3); fN += (o == 4);
+                if (q >= a.t + 33) low |= 1u << o;
+                sum += (u32)q;                                                 // wraps like the reference's int
+                if (q > mx) mx = q;
+            })
+        if (fA) atomicAdd(&S.freq[0], (u64)fA);
+        if (fC) atomicAdd(&S.freq[1], (u64)fC);
+        if (fG) atomicAdd(&S.freq[2], (u64)fG);
+        if (fT) atomicAdd(&S.freq[3], (u64)fT);
+        if (fN) atomicAdd(&S.freq[4], (u64)fN);
+        if (low) atomicOr(&S.low, low);
+        if (sum) atomicAdd(&S.sum, sum);
+        if (mx) atomicMax(&S.mx, (u32)mx);)
+}
+
+__global__ __launch_bounds__(256) void k_big_decide(ClusterArgs a)
+{
+    const u8 TERM = (u8)a.term;
+    const u64 nbig = a.cnt->bigClusters;
+    for (u64 bi = (u64)blockIdx.x * blockDim.x + threadIdx.x; bi < nbig; bi += (u64)gridDim.x * blockDim.x) {
+        BigState &S = a.big[bi];
+        const u64 start = S.start, end = S.end;
+        const u64 size = end - start + 1;
+        const u64 base_num = S.freq[0] + S.freq[1] + S.freq[2] + S.freq[3] + S.freq[4];
+        if (size < (u64)(long long)a.m) continue;
+        atomicAdd(&a.cnt->stats[0], 1ull);
+        if (!base_num) continue;
+        atomicAdd(&a.cnt->stats[5], base_num);
+        int newqs;
+        if (a.M == 1) {                                                        // rounding depends on the order: one thread, row order
+            double sum_err = 0;
+            for (u64 j = start; j <= end; j++)
+                if (a.bwt[j] != TERM) sum_err = sum_err + a.powtab[a.qual[j]];
+            double avg_err = sum_err / (double)base_num;
+            int lo = 0, hi = a.qthrN - 1;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (a.qthr[mid] <= avg_err) hi = mid; else lo = mid + 1; }
+            int q = a.qthrLo + lo;
+            newqs = a.ext ? (int)(signed char)(u8)((u8)q + 33) : (int)(signed char)(q + 33);
+        } else if (a.M == 2) {
+            newqs = (int)(signed char)a.v;
+        } else if (a.M == 3) {
+            int sum = (int)S.sum;
+            if (sum == 0) newqs = 0;
+            else if (a.ext) newqs = (int)(signed char)(u8)roundf((float)sum / (float)base_num);
+            else newqs = (int)(signed char)(int)((u64)(long long)sum / base_num);
+        } else {
+            newqs = (int)S.mx;
+        }
+        S.newqs = newqs;
+        u8 Freq[5];
+        int nf = 0, nnn = 0;
+        for (int s = 0; s < 5; s++)
+            if (S.freq[s] > 0) {
+                nnn++;
+                u32 perc = (u32)((100ull * S.freq[s]) / base_num) & 0xFFu;
+                if ((float)perc >= (float)a.f) Freq[nf++] = dna5(s);
+            }
+        if (nnn == 1) atomicAdd(&a.cnt->stats[4], 1ull);
+        if (nf >= 3) atomicAdd(&a.cnt->errFreq3, 1ull);
+        else if (nf == 0) atomicAdd(&a.cnt->stats[1], 1ull);
+        else if (nf == 1) {
+            if (Freq[0] == 'N') atomicAdd(&a.cnt->stats[1], 1ull);
+            else { S.mode = 1; S.sym0 = Freq[0]; }
+        } else if (base_num < (u64)(long long)a.m) atomicAdd(&a.cnt->stats[1], 1ull);
+        else if (Freq[0] == 'N') { S.mode = 1; S.sym0 = Freq[1]; atomicAdd(&a.cnt->stats[3], 1ull); }
+        else if (Freq[1] == 'N') { S.mode = 1; S.sym0 = Freq[0]; atomicAdd(&a.cnt->stats[3], 1ull); }
+        else { S.mode = 2; S.sym0 = Freq[0]; S.sym1 = Freq[1]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_big_prec(ClusterArgs a)
+{
+    const u8 TERM = (u8)a.term;
+    CB_FOR_TILES(
+        if (S.mode != 2) continue;
+        const u8 s0 = (u8)S.sym0; const u8 s1 = (u8)S.sym1;
+        u32 f0 = 0, f1 = 0;
+        CB_FOR_ROWS(
+            if (b == s0 || b == s1) {
+                const u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
+                if (ch != TERM && ch != 'N') { if (b == s0) f0 |= 1u << ord5(ch); else f1 |= 1u << ord5(ch); }
+            })
+        if (f0) atomicOr(&S.fr0, f0);
+        if (f1) atomicOr(&S.fr1, f1);)
+}
+
+__global__ __launch_bounds__(256) void k_big_apply(ClusterArgs a)
+{
+    const u8 TERM = (u8)a.term;
+    u32 modb = 0, qs = 0;
+    CB_FOR_TILES(
+        const int mode = S.mode; const int newqs = S.newqs;
+        const u32 lowQS = S.low;
+        const u8 s0 = (u8)S.sym0; const u8 s1 = (u8)S.sym1;
+        if (mode == 1) {                                                       // :376-405
+            CB_FOR_ROWS(
+                if (b != TERM) {
+                    if (b != s0 && !((lowQS >> ord5(b)) & 1u)) { set_mod(a, j, s0); modb++; }
+                    else if (b == s0) { set_qual(a, j, newqs); qs++; }
+                    else if (newqs < (int)(signed char)qb) { set_qual(a, j, newqs); qs++; }
+                })
+        } else if (mode == 2) {                                                // :568-591
+            const u32 f0 = S.fr0 & 15u; const u32 f1 = S.fr1 & 15u;
+            // with exactly one preceding symbol per frequent base, "the last one seen" is that symbol
+            const bool ok = __popc(f0) == 1 && __popc(f1) == 1 && f0 != f1;
+            if (t == 0 && threadIdx.x == 0) atomicAdd(&a.cnt->stats[ok ? 3 : 2], 1ull);
+            if (ok) {
+                const u8 p0 = dna5(__ffs(f0) - 1); const u8 p1 = dna5(__ffs(f1) - 1);
+                CB_FOR_ROWS(
+                    if (b != TERM) {
+                        if (b != s0 && b != s1 && !((lowQS >> ord5(b)) & 1u)) {
+                            const u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
+                            if (ch == p0) { set_mod(a, j, s0); modb++; }
+                            else if (ch == p1) { set_mod(a, j, s1); modb++; }
+                        } else if (b == s0 || b == s1) { set_qual(a, j, newqs); qs++; }
+                        else if (newqs < (int)(signed char)qb) { set_qual(a, j, newqs); qs++; }
+                    })
+            }
+        })
+    if (qs) atomicAdd(&a.cnt->stats[6], (u64)qs);
+    if (modb) atomicAdd(&a.cnt->stats[7], (u64)modb);
 }
 
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
@@ -451,9 +506,14 @@ void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual,
     a.cnt = c->d_cnt;
     size_t mk = c->mark();
     a.bigStart = c->alloc<u64>(n / CL_BIG + 2);
+    a.big = c->alloc<BigState>(n / CL_BIG + 2);
     u64 nchunks = ceil_div(n, CL_CHUNK);
     KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, bfq_grid(nchunks, 1), 256, a, nchunks);
-    // the list length stays on the device: a fixed grid strides over it (usually empty)
-    KLAUNCH(c, K_CLUSTER_BIG, 0.0, k_cluster_big, 1024, 256, a);
+    // the list length stays on the device: fixed grids stride over it (usually empty)
+    KLAUNCH(c, K_CLUSTER_BIG, 0.0, k_big_extent, 1024, 256, a);
+    KLAUNCH(c, K_CLUSTER_BIG, 0.0, k_big_count, CB_GRID, 256, a);
+    KLAUNCH(c, K_CLUSTER_BIG, 0.0, k_big_decide, 64, 256, a);
+    KLAUNCH(c, K_CLUSTER_BIG, 0.0, k_big_prec, CB_GRID, 256, a);
+    KLAUNCH(c, K_CLUSTER_BIG, 0.0, k_big_apply, CB_GRID, 256, a);
     c->release(mk);
 }

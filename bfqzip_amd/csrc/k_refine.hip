@@ -69,7 +69,8 @@ __device__ __forceinline__ void wo_key2(const u64 *__restrict__ text3, u64 v, u3
 }
 
 __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restrict__ lcp, const u64 *__restrict__ text3,
-                                                      u64 n, u64 *__restrict__ biglist, DevCounters *cnt, u64 nchunks)
+                                                      u64 n, u64 *__restrict__ biglist, DevCounters *cnt, u64 nchunks,
+                                                      u16 *__restrict__ firstHead)
 {
     // every wavefront works alone on its own chunk (no workgroup barriers): private LDS slices
     __shared__ u64 hb_all[4][RF_HBW];               // head bits of rows [base, base + RF_CHUNK + 256)
@@ -123,6 +124,12 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
         {
             const bool on = lane < RF_CHUNK / 64;
             const u64 hw = on ? hb[lane] : ~0ull, hn = on ? hb[lane + 1] : ~0ull;
+            {                                                      // first head row of the chunk (RF_CHUNK: none), for k_refine_big's search
+                const u64 any = __ballot(on && hw != 0);
+                const int fl = any ? __builtin_ctzll(any) : -1;
+                const u64 fw = bfq_readlane64(hw, fl < 0 ? 0 : fl);
+                if (lane == 0) firstHead[ch] = (u16)(fl < 0 ? RF_CHUNK : fl * 64 + __builtin_ctzll(fw));
+            }
             u64 S = on ? (hw & ~((hw >> 1) | (hn << 63))) : 0ull;   // head followed by a non-head (rows past n are heads)
             const u32 c = (u32)__popcll(S);
             const u32 incl = bfq_wave_incscan32(c);
@@ -280,7 +287,8 @@ __device__ void big_sort(const SortRec &rec, u64 s, u64 g, const u64 *__restrict
 
 __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ biglist, DevCounters *cnt, SortRec rec,
                                                     u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
-                                                    u64 *__restrict__ hugeStart, u64 *__restrict__ hugeLen)
+                                                    u64 *__restrict__ hugeStart, u64 *__restrict__ hugeLen,
+                                                    const u16 *__restrict__ firstHead)
 {
     __shared__ u64 shEnd;
     const u64 nbig = cnt->bigCount;
@@ -289,20 +297,33 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
         __syncthreads();
         if (threadIdx.x == 0) shEnd = ~0ull;
         __syncthreads();
-        for (u64 b0 = s + 1;; b0 += 256 * 8) {         // first head after s = end of the segment
-            u64 i0 = b0 + (u64)threadIdx.x * 8;
-            u64 kp = (i0 < n) ? rec_key(rec, i0 - 1) : 0ull;
-            for (u32 k = 0; k < 8; k++) {
-                u64 i = i0 + k;
-                if (i >= n) { atomicMin(&shEnd, i); break; }
-                u64 kc = rec_key(rec, i);
-                if (seg_head(kp, kc)) { atomicMin(&shEnd, i); break; }
-                kp = kc;
+        // first head after s = end of the segment: the rest of s's chunk row by row, then whole chunks by
+        // their first-head entries (256 chunks = 524288 rows per step)
+        {
+            const u64 cend = (s / RF_CHUNK + 1) * RF_CHUNK;
+            for (u64 b0 = s + 1; b0 < cend; b0 += 256 * 8) {
+                u64 i0 = b0 + (u64)threadIdx.x * 8;
+                u64 kp = (i0 < n && i0 < cend) ? rec_key(rec, i0 - 1) : 0ull;
+                for (u32 k = 0; k < 8; k++) {
+                    u64 i = i0 + k;
+                    if (i >= cend) break;
+                    if (i >= n) { atomicMin(&shEnd, i); break; }
+                    u64 kc = rec_key(rec, i);
+                    if (seg_head(kp, kc)) { atomicMin(&shEnd, i); break; }
+                    kp = kc;
+                }
             }
             __syncthreads();
-            bool done = (shEnd != ~0ull);
-            __syncthreads();
-            if (done) break;                           // uniform
+            const u64 nch = (n + RF_CHUNK - 1) / RF_CHUNK;
+            for (u64 c0 = s / RF_CHUNK + 1;; c0 += 256) {
+                bool done = (shEnd != ~0ull);
+                __syncthreads();
+                if (done) break;                       // uniform
+                u64 ch = c0 + threadIdx.x;
+                if (ch >= nch) atomicMin(&shEnd, n);
+                else { u32 fh = firstHead[ch]; if (fh < RF_CHUNK) atomicMin(&shEnd, ch * RF_CHUNK + fh); }
+                __syncthreads();
+            }
         }
         const u64 g = shEnd - s;
         if (g > BFQ_HUGE_SEG) {                        // uniform: left to the radix rounds
@@ -371,13 +392,15 @@ void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_
     size_t m = c->mark();
     u64 *biglist = c->alloc<u64>(n / 65 + 2);
     u64 nchunks = ceil_div(n, RF_CHUNK);
+    u16 *firstHead = c->alloc<u16>(nchunks + 1);
     // remaining packed suffix read once (3(L+1)/16 B) + order 8 B + LCP 1 B per row
     const double lavg = c->N ? (double)(n - c->N) / (double)c->N : 0.0;
     KLAUNCH(c, K_REFINE_WAVE, (3.0 * (lavg + 1.0) / 16.0 + 9.0) * (double)n, k_refine_chunk, bfq_grid(nchunks, 4), 256, rec, lcp, text3, n, biglist,
-            c->d_cnt, nchunks);
+            c->d_cnt, nchunks, firstHead);
     u64 *hugeStart = c->alloc<u64>(n / BFQ_HUGE_SEG + 2), *hugeLen = c->alloc<u64>(n / BFQ_HUGE_SEG + 2);
     // the list length stays on the device: a fixed grid strides over it (usually empty)
-    KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, 1024, 256, (const u64 *)biglist, c->d_cnt, rec, lcp, text3, n, hugeStart, hugeLen);
+    KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, 1024, 256, (const u64 *)biglist, c->d_cnt, rec, lcp, text3, n, hugeStart, hugeLen,
+            (const u16 *)firstHead);
     bfq_refine_huge(c, rec, text3, n, lcp, hugeStart, hugeLen);
     c->release(m);
 }
