@@ -271,3 +271,24 @@ def test_low_complexity_collections(engine, orc, monkeypatch):
     assert st["n_big_segments"] > 0
     monkeypatch.setenv("BFQ_HUGE_CAP", "60000")
     _check_against_oracle(engine, orc, b, q, r, m=2, k=20)
+
+
+def test_long_cluster_two_frequent_bases(engine, orc):
+    """A cluster of 6 000 rows whose eBWT symbols are C and G half and half, each with its own preceding base: the
+    two-frequent-symbol branch (bfq_int.cpp:542-591) inside the tiled long-cluster kernels, incl. base replacement."""
+    rng = np.random.default_rng(11)
+    ACGT = np.array(list(b"ACGT"), np.uint8)
+    U = ACGT[rng.integers(0, 4, 60)]
+    mk = lambda pre: np.concatenate([np.frombuffer(pre, np.uint8), U])
+    reads = [mk(b"AC")] * 3000 + [mk(b"TG")] * 3000 + [mk(b"AT")] * 40 + [mk(b"TA")] * 40
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    b = np.concatenate(reads)
+    q = rng.integers(33, 74, len(b)).astype(np.uint8)
+    r = np.zeros(len(reads) + 1, np.uint64)
+    r[1:] = np.cumsum([len(x) for x in reads])
+    for i, x in enumerate(reads):                                      # the odd bases before U are never trusted (-t 20)
+        if bytes(x[:2]) in (b"AT", b"TA"):
+            q[int(r[i]) + 1] = 35
+    for M in (2, 0, 1, 3):
+        st = _check_against_oracle(engine, orc, b, q, r, M=M, m=5)
+        assert st["num_clust_mod"] > 0 and st["modified"] > 0
