@@ -65,6 +65,7 @@ struct ClusterArgs {
     DevCounters *cnt;
     u64 *bigStart;          // first in() rows of the clusters left to the k_big_* kernels
     struct BigState *big;   // their state
+    u16 *firstOut;          // per CL_WROWS rows: first row with in() == 0 (CL_WROWS: none), for k_big_extent
 };
 
 __device__ __forceinline__ int ord5(u8 c)   // bfq_int.cpp:106-110: A0 C1 G2 T3 N4
@@ -244,6 +245,13 @@ __global__ __launch_bounds__(256) void k_cluster(ClusterArgs a, u64 nchunks)
                 for (int b = 0; b < 4; b++) bits |= ((wds[q] >> (8 * b)) & 1u) << (4 * q + b);
             if (r0 + 16 > a.n) bits &= (1u << (u32)(a.n - r0)) - 1u;
         }
+        {                                                          // first row of this wave's 1024 that is outside every cluster
+            const u32 zb = ~bits & 0xFFFFu;
+            const u64 any = __ballot(zb != 0);
+            const int fl = any ? __builtin_ctzll(any) : -1;
+            const u32 fz = (u32)__builtin_amdgcn_readlane((int)zb, fl < 0 ? 0 : fl);
+            if (lane == 0) a.firstOut[ch * 4 + w] = (u16)(fl < 0 ? CL_WROWS : fl * (CL_WROWS / 64) + __builtin_ctz(fz));
+        }
         u32 prev = (r0 >= 1 && r0 < a.n) ? (u32)a.in[r0 - 1] & 1u : 0u;
         u32 sb = bits & ~((bits << 1) | prev) & 0xFFFFu;           // cluster starts: in(r) && !in(r-1)
         u32 ns = (u32)__popc(sb);
@@ -333,21 +341,32 @@ __global__ __launch_bounds__(256) void k_big_extent(ClusterArgs a)
         __syncthreads();
         if (threadIdx.x == 0) shEnd = ~0ull;
         __syncthreads();
-        for (u64 b0 = (r + 1) & ~15ull;; b0 += 256 * 16) {           // 16 flags per thread and step (in[] is padded)
-            const u64 i0 = b0 + (u64)threadIdx.x * 16;
-            if (i0 < a.n + 16) {
-                const uint4 x = *(const uint4 *)(a.in + i0);
-                const u32 wds[4] = {x.x, x.y, x.z, x.w};
-                for (u32 k = 0; k < 16; k++) {
-                    const u64 xr = i0 + k;
-                    if (xr <= r) continue;
-                    if (xr >= a.n || !((wds[k >> 2] >> (8 * (k & 3))) & 1u)) { atomicMin(&shEnd, xr); break; }
+        // the rest of r's 1024-row piece flag by flag, then whole pieces by their first-out entries
+        {
+            const u64 pend = ((r + 1) / CL_WROWS + 1) * CL_WROWS;
+            for (u64 b0 = (r + 1) & ~15ull; b0 < pend; b0 += 256 * 16) {
+                const u64 i0 = b0 + (u64)threadIdx.x * 16;
+                if (i0 < pend && i0 < a.n + 16) {
+                    const uint4 x = *(const uint4 *)(a.in + i0);
+                    const u32 wds[4] = {x.x, x.y, x.z, x.w};
+                    for (u32 k = 0; k < 16; k++) {
+                        const u64 xr = i0 + k;
+                        if (xr <= r) continue;
+                        if (xr >= a.n || !((wds[k >> 2] >> (8 * (k & 3))) & 1u)) { atomicMin(&shEnd, xr); break; }
+                    }
                 }
             }
             __syncthreads();
-            bool done = (shEnd != ~0ull);
-            __syncthreads();
-            if (done) break;
+            const u64 npieces = (a.n + CL_WROWS - 1) / CL_WROWS;
+            for (u64 p0 = pend / CL_WROWS;; p0 += 256) {
+                bool done = (shEnd != ~0ull);
+                __syncthreads();
+                if (done) break;                       // uniform
+                const u64 pc = p0 + threadIdx.x;
+                if (pc >= npieces) atomicMin(&shEnd, a.n);
+                else { const u32 fo = a.firstOut[pc]; if (fo < CL_WROWS) atomicMin(&shEnd, pc * CL_WROWS + fo); }
+                __syncthreads();
+            }
         }
         if (threadIdx.x == 0) {
             BigState z = {};
@@ -507,6 +526,7 @@ void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual,
     size_t mk = c->mark();
     a.bigStart = c->alloc<u64>(n / CL_BIG + 2);
     a.big = c->alloc<BigState>(n / CL_BIG + 2);
+    a.firstOut = c->alloc<u16>(n / CL_WROWS + 8);
     u64 nchunks = ceil_div(n, CL_CHUNK);
     KLAUNCH(c, K_CLUSTER, 4.125 * (double)n, k_cluster, bfq_grid(nchunks, 1), 256, a, nchunks);
     // the list length stays on the device: fixed grids stride over it (usually empty)
