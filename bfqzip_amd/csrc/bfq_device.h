@@ -15,12 +15,6 @@ __device__ __forceinline__ u64 bfq_readlane64(u64 v, int srcLane)   // srcLane w
     u32 hi = (u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), srcLane);
     return ((u64)hi << 32) | lo;
 }
-__device__ __forceinline__ u64 bfq_bpermute64(u64 v, int srcLane)    // pull from any lane
-{
-    u32 lo = (u32)__builtin_amdgcn_ds_bpermute(srcLane << 2, (int)(u32)v);
-    u32 hi = (u32)__builtin_amdgcn_ds_bpermute(srcLane << 2, (int)(u32)(v >> 32));
-    return ((u64)hi << 32) | lo;
-}
 __device__ __forceinline__ u64 bfq_permute64(u64 v, int dstLane)     // push to a lane (dstLane a permutation)
 {
     u32 lo = (u32)__builtin_amdgcn_ds_permute(dstLane << 2, (int)(u32)v);

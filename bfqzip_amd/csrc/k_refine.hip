@@ -45,16 +45,6 @@ __device__ __forceinline__ u64 wo_to_pay(u64 v)
     u64 p = w * BFQ_SYMS_PER_WORD + o3 / 3ull - BFQ_KEY_SYMS;
     return bfq_pack_val(p, (u32)(v >> 40) & 7u, (u32)(v >> 43) & 0xFFu);
 }
-// masked 21-symbol window `round` words further along the suffix
-__device__ __forceinline__ u64 wo_key(const u64 *__restrict__ text3, u64 v, u32 round)
-{
-    u64 w = (v & ((1ull << 34) - 1ull)) + round;
-    u32 o = (u32)(v >> 34) & 63u;
-    u64 hi = (text3[w] << o) & BFQ_M63;
-    u64 lo = o ? (text3[w + 1] >> (63u - o)) : 0ull;
-    return bfq_mask_key(hi | lo);
-}
-
 // the two consecutive masked windows `round` and `round + 1` words along the suffix (three text words);
 // the second one is 0 when the first already holds the terminator
 __device__ __forceinline__ void wo_key2(const u64 *__restrict__ text3, u64 v, u32 round, u64 &W1, u64 &W2)
