@@ -21,7 +21,7 @@
 #define RS_OCC (1024 / RS_THREADS)                  // workgroups per CU (16 waves); 512-thread tiles measured 40 % slower
 #define RS_ROUNDS 12                                // items per thread
 #define RS_TILE (RS_THREADS * RS_ROUNDS)            // 3072 records per tile
-#define RS_TILES_PER_BLOCK 8
+#define RS_TILES_PER_BLOCK 32
 #define RS_BLOCK_ELEMS ((u64)RS_TILE * RS_TILES_PER_BLOCK)
 
 template <class T>
