@@ -134,7 +134,7 @@ void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes = 6);   
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
 void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
 // segments above BFQ_HUGE_SEG rows (listed by k_refine_big): whole-device radix rounds on the following symbols
-#define BFQ_HUGE_SEG 4096
+#define BFQ_HUGE_SEG 2048
 void bfq_refine_huge(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, const u64 *hugeStart, const u64 *hugeLen);
 void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs, u32 *gcnt);   // gcnt: [6][n/256+1] symbol counts
 // whole step 1 on device-resident reads; leaves c->d_bwt/d_qual/d_lcp

@@ -275,12 +275,113 @@ __device__ void big_sort(const SortRec &rec, u64 s, u64 g, const u64 *__restrict
         lcp[s + i] = (u16)suffix_lcp(text3, bfq_val_pos(rec_pay(rec, s + i - 1)), bfq_val_pos(rec_pay(rec, s + i)));
 }
 
+// ---- segments of 65 .. BFQ_HUGE_SEG rows: one workgroup each, everything in LDS ------------------------
+// Round by round (42 symbols each) like the wavefront kernel, but the stable rank comes from a bitonic network
+// over (sub-segment id, next word, original slot) kept in LDS: every row's next word is fetched once per
+// round, no suffix is compared through global memory.  Slot i of the segment is eBWT row s + i throughout, so
+// the LCP of a boundary is final the moment the boundary appears.
+#define RB_MAX BFQ_HUGE_SEG
+struct BlockSortLds {
+    u64 W1[RB_MAX], W2[RB_MAX];   // next two words of the row now in slot i (0 for rows that are already alone)
+    u32 T[RB_MAX];        // sub-segment id << 12 | original slot (padding: all ones)
+    u64 V[RB_MAX];        // by ORIGINAL slot: working form of the payload (word index / offset of p + 16)
+    u32 scan[4];
+    u32 open;
+};
+__device__ __forceinline__ bool rb_less(u32 ta, u64 a1, u64 a2, u32 tb, u64 b1, u64 b2)
+{
+    const u32 sa = ta >> 12, sb = tb >> 12;
+    if (sa != sb) return sa < sb;
+    if (a1 != b1) return a1 < b1;
+    if (a2 != b2) return a2 < b2;
+    return (ta & 0xFFFu) < (tb & 0xFFFu);
+}
+__device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restrict__ text3, u16 *__restrict__ lcp, BlockSortLds &L)
+{
+    const u32 tid = threadIdx.x;
+    u32 P = 128;
+    while (P < g) P <<= 1;
+    for (u32 i = tid; i < P; i += 256) {
+        if (i < g) { L.V[i] = wo_from_pay(rec_pay(rec, s + i)); L.T[i] = i; }
+        else { L.T[i] = 0xFFFFFFFFu; L.W1[i] = ~0ull; L.W2[i] = ~0ull; }
+    }
+    __syncthreads();
+    u32 depth = BFQ_KEY_SYMS;
+    for (u32 round = 0;; round += 2, depth += 2 * BFQ_SYMS_PER_WORD) {        // one round = the next 42 symbols
+        // next words of every row that still shares its sub-segment with a neighbour
+        for (u32 i = tid; i < g; i += 256) {
+            const u32 t = L.T[i], sub = t >> 12;
+            const bool alone = (i == 0 || (L.T[i - 1] >> 12) != sub) && (i + 1 >= g || (L.T[i + 1] >> 12) != sub);
+            u64 w1 = 0, w2 = 0;
+            if (!alone) wo_key2(text3, L.V[t & 0xFFFu], round, w1, w2);
+            L.W1[i] = w1; L.W2[i] = w2;
+        }
+        __syncthreads();
+        // bitonic network on (sub-segment, words, original slot); padding sorts last
+        for (u32 k = 2; k <= P; k <<= 1)
+            for (u32 j = k >> 1; j >= 1; j >>= 1) {
+                for (u32 c = tid; c < P / 2; c += 256) {
+                    const u32 lo = ((c & ~(j - 1)) << 1) | (c & (j - 1)), hi = lo | j;
+                    const bool up = (lo & k) == 0;
+                    const u32 ta = L.T[lo], tb = L.T[hi];
+                    const u64 a1 = L.W1[lo], b1 = L.W1[hi], a2 = L.W2[lo], b2 = L.W2[hi];
+                    if (rb_less(tb, b1, b2, ta, a1, a2) == up) {
+                        L.T[lo] = tb; L.T[hi] = ta; L.W1[lo] = b1; L.W1[hi] = a1; L.W2[lo] = b2; L.W2[hi] = a2;
+                    }
+                }
+                __syncthreads();
+            }
+        // new boundaries, their LCP, new dense sub-segment ids (block scan of the head flags, 8 slots per thread at most)
+        u32 heads = 0, cnt = 0;
+        const u32 per = P / 256 ? P / 256 : 1, i0 = tid * per;
+        for (u32 q = 0; q < per; q++) {
+            const u32 i = i0 + q;
+            if (i >= g || (P < 256 && tid >= P)) break;
+            bool h = true;
+            if (i) {
+                const u32 t = L.T[i], tp = L.T[i - 1];
+                const u64 w1 = L.W1[i], p1 = L.W1[i - 1], w2 = L.W2[i], p2 = L.W2[i - 1];
+                const bool sameSub = (t >> 12) == (tp >> 12);
+                const bool d1 = w1 != p1 || bfq_key_has_term(w1);                  // decided by the first word
+                h = !sameSub || d1 || w2 != p2 || bfq_key_has_term(w2);
+                if (sameSub && h)
+                    lcp[s + i] = (u16)(d1 ? depth + (u32)bfq_key_lcp(p1, w1) : depth + BFQ_SYMS_PER_WORD + (u32)bfq_key_lcp(p2, w2));
+            }
+            heads |= (h ? 1u : 0u) << q;
+            cnt += h ? 1u : 0u;
+        }
+        u32 total;
+        u32 ex = bfq_block_exscan32(cnt, L.scan, &total);          // two barriers inside: all reads of T above are done
+        if (tid == 0) L.open = 0;
+        __syncthreads();
+        u32 id = ex;                                                // heads before my first slot
+        bool anyOpen = false;
+        for (u32 q = 0; q < per; q++) {
+            const u32 i = i0 + q;
+            if (i >= g || (P < 256 && tid >= P)) break;
+            if ((heads >> q) & 1u) id++;
+            else anyOpen = true;                                    // a slot that is not a head shares its sub-segment
+            L.T[i] = ((id - 1) << 12) | (L.T[i] & 0xFFFu);
+        }
+        if (anyOpen) L.open = 1;
+        __syncthreads();
+        if (!L.open) break;                                         // uniform
+    }
+    // final order: slot i takes the payload of original slot T[i] & 0xFFF (all reads before any write)
+    u64 pay[RB_MAX / 256];
+    for (u32 q = 0, i = tid; i < g; i += 256, q++) pay[q] = rec_pay(rec, s + (L.T[i] & 0xFFFu));
+    __syncthreads();
+    for (u32 q = 0, i = tid; i < g; i += 256, q++) rec_set_pay(rec, s + i, pay[q]);
+    __syncthreads();
+}
+
 __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ biglist, DevCounters *cnt, SortRec rec,
                                                     u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
                                                     u64 *__restrict__ hugeStart, u64 *__restrict__ hugeLen,
                                                     const u16 *__restrict__ firstHead)
 {
     __shared__ u64 shEnd;
+    __shared__ BlockSortLds L;
     const u64 nbig = cnt->bigCount;
     for (u64 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         const u64 s = biglist[bi];
@@ -324,11 +425,11 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
             }
             continue;
         }
-        big_sort(rec, s, g, text3, lcp);
+        block_sort(rec, s, (u32)g, text3, lcp, L);
     }
 }
 
-// the same network for listed segments of known length (huge segments that did not fit the radix rounds' workspace)
+// the global-memory network for listed segments of known length (huge segments that did not fit the radix rounds' workspace)
 __global__ __launch_bounds__(256) void k_refine_listed(const u64 *__restrict__ start, const u64 *__restrict__ len, u64 count, SortRec rec,
                                                        u16 *__restrict__ lcp, const u64 *__restrict__ text3)
 {
