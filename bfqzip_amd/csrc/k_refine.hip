@@ -280,14 +280,20 @@ __device__ void big_sort(const SortRec &rec, u64 s, u64 g, const u64 *__restrict
 // over (sub-segment id, next word, original slot) kept in LDS: every row's next word is fetched once per
 // round, no suffix is compared through global memory.  Slot i of the segment is eBWT row s + i throughout, so
 // the LCP of a boundary is final the moment the boundary appears.
-#define RB_MAX BFQ_HUGE_SEG
-struct BlockSortLds {
-    u64 W1[RB_MAX], W2[RB_MAX];   // next two words of the row now in slot i (0 for rows that are already alone)
-    u32 T[RB_MAX];        // sub-segment id << 12 | original slot (padding: all ones)
-    u64 V[RB_MAX];        // by ORIGINAL slot: working form of the payload (word index / offset of p + 16)
+// Three size classes: one wavefront (64 threads, no real barriers) for segments up to RB_SMALL rows, 128 threads up to
+// twice that, 256 threads up to BFQ_HUGE_SEG (one wavefront for the larger classes measured slower: LDS latency).
+#define RB_SMALL 512
+template <int PMAX> struct BlockSortLds {
+    u64 W1[PMAX], W2[PMAX];   // next two words of the row now in slot i (0 for rows that are already alone)
+    u32 T[PMAX];          // sub-segment id << 12 | original slot (padding: all ones)
+    u64 V[PMAX];          // by ORIGINAL slot: working form of the payload (word index / offset of p + 16)
     u32 scan[4];
     u32 open;
 };
+template <int NT> __device__ __forceinline__ void grp_sync()
+{
+    if (NT == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+}
 __device__ __forceinline__ bool rb_less(u32 ta, u64 a1, u64 a2, u32 tb, u64 b1, u64 b2)
 {
     const u32 sa = ta >> 12, sb = tb >> 12;
@@ -296,31 +302,32 @@ __device__ __forceinline__ bool rb_less(u32 ta, u64 a1, u64 a2, u32 tb, u64 b1, 
     if (a2 != b2) return a2 < b2;
     return (ta & 0xFFFu) < (tb & 0xFFFu);
 }
-__device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restrict__ text3, u16 *__restrict__ lcp, BlockSortLds &L)
+template <int NT, int PMAX>
+__device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restrict__ text3, u16 *__restrict__ lcp, BlockSortLds<PMAX> &L)
 {
     const u32 tid = threadIdx.x;
     u32 P = 128;
     while (P < g) P <<= 1;
-    for (u32 i = tid; i < P; i += 256) {
+    for (u32 i = tid; i < P; i += NT) {
         if (i < g) { L.V[i] = wo_from_pay(rec_pay(rec, s + i)); L.T[i] = i; }
         else { L.T[i] = 0xFFFFFFFFu; L.W1[i] = ~0ull; L.W2[i] = ~0ull; }
     }
-    __syncthreads();
+    grp_sync<NT>();
     u32 depth = BFQ_KEY_SYMS;
     for (u32 round = 0;; round += 2, depth += 2 * BFQ_SYMS_PER_WORD) {        // one round = the next 42 symbols
         // next words of every row that still shares its sub-segment with a neighbour
-        for (u32 i = tid; i < g; i += 256) {
+        for (u32 i = tid; i < g; i += NT) {
             const u32 t = L.T[i], sub = t >> 12;
             const bool alone = (i == 0 || (L.T[i - 1] >> 12) != sub) && (i + 1 >= g || (L.T[i + 1] >> 12) != sub);
             u64 w1 = 0, w2 = 0;
             if (!alone) wo_key2(text3, L.V[t & 0xFFFu], round, w1, w2);
             L.W1[i] = w1; L.W2[i] = w2;
         }
-        __syncthreads();
+        grp_sync<NT>();
         // bitonic network on (sub-segment, words, original slot); padding sorts last
         for (u32 k = 2; k <= P; k <<= 1)
             for (u32 j = k >> 1; j >= 1; j >>= 1) {
-                for (u32 c = tid; c < P / 2; c += 256) {
+                for (u32 c = tid; c < P / 2; c += NT) {
                     const u32 lo = ((c & ~(j - 1)) << 1) | (c & (j - 1)), hi = lo | j;
                     const bool up = (lo & k) == 0;
                     const u32 ta = L.T[lo], tb = L.T[hi];
@@ -329,14 +336,14 @@ __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restri
                         L.T[lo] = tb; L.T[hi] = ta; L.W1[lo] = b1; L.W1[hi] = a1; L.W2[lo] = b2; L.W2[hi] = a2;
                     }
                 }
-                __syncthreads();
+                grp_sync<NT>();
             }
         // new boundaries, their LCP, new dense sub-segment ids (block scan of the head flags, 8 slots per thread at most)
         u32 heads = 0, cnt = 0;
-        const u32 per = P / 256 ? P / 256 : 1, i0 = tid * per;
+        const u32 per = P / NT ? P / NT : 1, i0 = tid * per;
         for (u32 q = 0; q < per; q++) {
             const u32 i = i0 + q;
-            if (i >= g || (P < 256 && tid >= P)) break;
+            if (i >= g || (P < NT && tid >= P)) break;
             bool h = true;
             if (i) {
                 const u32 t = L.T[i], tp = L.T[i - 1];
@@ -350,49 +357,61 @@ __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restri
             heads |= (h ? 1u : 0u) << q;
             cnt += h ? 1u : 0u;
         }
-        u32 total;
-        u32 ex = bfq_block_exscan32(cnt, L.scan, &total);          // two barriers inside: all reads of T above are done
+        u32 ex = bfq_wave_incscan32(cnt) - cnt;                     // exclusive scan over the NT threads
+        if (NT > 64) {
+            const u32 w = tid >> 6;
+            if ((tid & 63u) == 63u) L.scan[w] = ex + cnt;
+            __syncthreads();
+            for (u32 k = 0; k < w; k++) ex += L.scan[k];
+        }
+        grp_sync<NT>();                                             // all reads of T above are done
         if (tid == 0) L.open = 0;
-        __syncthreads();
+        grp_sync<NT>();
         u32 id = ex;                                                // heads before my first slot
         bool anyOpen = false;
         for (u32 q = 0; q < per; q++) {
             const u32 i = i0 + q;
-            if (i >= g || (P < 256 && tid >= P)) break;
+            if (i >= g || (P < NT && tid >= P)) break;
             if ((heads >> q) & 1u) id++;
             else anyOpen = true;                                    // a slot that is not a head shares its sub-segment
             L.T[i] = ((id - 1) << 12) | (L.T[i] & 0xFFFu);
         }
         if (anyOpen) L.open = 1;
-        __syncthreads();
+        grp_sync<NT>();
         if (!L.open) break;                                         // uniform
     }
     // final order: slot i takes the payload of original slot T[i] & 0xFFF (all reads before any write)
-    u64 pay[RB_MAX / 256];
-    for (u32 q = 0, i = tid; i < g; i += 256, q++) pay[q] = rec_pay(rec, s + (L.T[i] & 0xFFFu));
-    __syncthreads();
-    for (u32 q = 0, i = tid; i < g; i += 256, q++) rec_set_pay(rec, s + i, pay[q]);
-    __syncthreads();
+    u64 pay[PMAX / NT];
+    for (u32 q = 0, i = tid; i < g; i += NT, q++) pay[q] = rec_pay(rec, s + (L.T[i] & 0xFFFu));
+    grp_sync<NT>();
+    for (u32 q = 0, i = tid; i < g; i += NT, q++) rec_set_pay(rec, s + i, pay[q]);
+    grp_sync<NT>();
 }
 
-__global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ biglist, DevCounters *cnt, SortRec rec,
-                                                    u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
-                                                    u64 *__restrict__ hugeStart, u64 *__restrict__ hugeLen,
-                                                    const u16 *__restrict__ firstHead)
+// One workgroup of NT threads per listed segment.  The 64-thread launch comes first: it finds every segment's
+// extent (kept in biglen) and sorts those of up to RB_SMALL rows; the 128- and 256-thread launches take the next
+// two size classes (their LDS footprint sets how many run per CU), the last one lists what is longer than
+// BFQ_HUGE_SEG rows for the radix rounds.
+template <int NT, int PMAX, bool FIRST>
+__global__ __launch_bounds__(NT) void k_refine_big(const u64 *__restrict__ biglist, u64 *__restrict__ biglen, DevCounters *cnt, SortRec rec,
+                                                   u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
+                                                   u64 *__restrict__ hugeStart, u64 *__restrict__ hugeLen,
+                                                   const u16 *__restrict__ firstHead)
 {
     __shared__ u64 shEnd;
-    __shared__ BlockSortLds L;
+    __shared__ BlockSortLds<PMAX> L;
     const u64 nbig = cnt->bigCount;
     for (u64 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         const u64 s = biglist[bi];
-        __syncthreads();
-        if (threadIdx.x == 0) shEnd = ~0ull;
-        __syncthreads();
-        // first head after s = end of the segment: the rest of s's chunk row by row, then whole chunks by
-        // their first-head entries (256 chunks = 524288 rows per step)
-        {
+        u64 g;
+        if (FIRST) {
+            grp_sync<NT>();
+            if (threadIdx.x == 0) shEnd = ~0ull;
+            grp_sync<NT>();
+            // first head after s = end of the segment: the rest of s's chunk 512 rows at a time, then whole chunks
+            // by their first-head entries
             const u64 cend = (s / RF_CHUNK + 1) * RF_CHUNK;
-            for (u64 b0 = s + 1; b0 < cend; b0 += 256 * 8) {
+            for (u64 b0 = s + 1; b0 < cend; b0 += NT * 8) {
                 u64 i0 = b0 + (u64)threadIdx.x * 8;
                 u64 kp = (i0 < n && i0 < cend) ? rec_key(rec, i0 - 1) : 0ull;
                 for (u32 k = 0; k < 8; k++) {
@@ -403,29 +422,38 @@ __global__ __launch_bounds__(256) void k_refine_big(const u64 *__restrict__ bigl
                     if (seg_head(kp, kc)) { atomicMin(&shEnd, i); break; }
                     kp = kc;
                 }
+                grp_sync<NT>();
+                if (shEnd != ~0ull) break;             // uniform
             }
-            __syncthreads();
+            grp_sync<NT>();
             const u64 nch = (n + RF_CHUNK - 1) / RF_CHUNK;
-            for (u64 c0 = s / RF_CHUNK + 1;; c0 += 256) {
+            for (u64 c0 = s / RF_CHUNK + 1;; c0 += NT) {
                 bool done = (shEnd != ~0ull);
-                __syncthreads();
+                grp_sync<NT>();
                 if (done) break;                       // uniform
                 u64 ch = c0 + threadIdx.x;
                 if (ch >= nch) atomicMin(&shEnd, n);
                 else { u32 fh = firstHead[ch]; if (fh < RF_CHUNK) atomicMin(&shEnd, ch * RF_CHUNK + fh); }
-                __syncthreads();
+                grp_sync<NT>();
             }
-        }
-        const u64 g = shEnd - s;
-        if (g > BFQ_HUGE_SEG) {                        // uniform: left to the radix rounds
-            if (threadIdx.x == 0) {
-                u64 h = atomicAdd(&cnt->hugeCount, 1ull);
-                atomicAdd(&cnt->hugeRows, g);
-                hugeStart[h] = s; hugeLen[h] = g;
+            g = shEnd - s;
+            if (threadIdx.x == 0) biglen[bi] = g;
+            if (g > PMAX) continue;                    // uniform
+        } else {
+            g = biglen[bi];
+            if (g <= PMAX / 2) continue;               // done by a smaller launch
+            if (g > BFQ_HUGE_SEG) {                    // uniform: left to the radix rounds
+                if (PMAX == BFQ_HUGE_SEG && threadIdx.x == 0) {
+                    u64 h = atomicAdd(&cnt->hugeCount, 1ull);
+                    atomicAdd(&cnt->hugeRows, g);
+                    hugeStart[h] = s; hugeLen[h] = g;
+                }
+                continue;
             }
-            continue;
+            if (g > PMAX) continue;                    // a larger launch's
+            grp_sync<NT>();
         }
-        block_sort(rec, s, (u32)g, text3, lcp, L);
+        block_sort<NT, PMAX>(rec, s, (u32)g, text3, lcp, L);
     }
 }
 
@@ -490,8 +518,13 @@ void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_
             c->d_cnt, nchunks, firstHead);
     u64 *hugeStart = c->alloc<u64>(n / BFQ_HUGE_SEG + 2), *hugeLen = c->alloc<u64>(n / BFQ_HUGE_SEG + 2);
     // the list length stays on the device: a fixed grid strides over it (usually empty)
-    KLAUNCH(c, K_REFINE_BIG, 0.0, k_refine_big, 1024, 256, (const u64 *)biglist, c->d_cnt, rec, lcp, text3, n, hugeStart, hugeLen,
-            (const u16 *)firstHead);
+    u64 *biglen = c->alloc<u64>(n / 65 + 2);
+    KLAUNCH(c, K_REFINE_BIG, 0.0, (k_refine_big<64, RB_SMALL, true>), 4096, 64, (const u64 *)biglist, biglen, c->d_cnt, rec, lcp, text3, n,
+            hugeStart, hugeLen, (const u16 *)firstHead);
+    KLAUNCH(c, K_REFINE_BIG, 0.0, (k_refine_big<128, 2 * RB_SMALL, false>), 2048, 128, (const u64 *)biglist, biglen, c->d_cnt, rec, lcp, text3, n,
+            hugeStart, hugeLen, (const u16 *)firstHead);
+    KLAUNCH(c, K_REFINE_BIG, 0.0, (k_refine_big<256, BFQ_HUGE_SEG, false>), 1024, 256, (const u64 *)biglist, biglen, c->d_cnt, rec, lcp, text3, n,
+            hugeStart, hugeLen, (const u16 *)firstHead);
     bfq_refine_huge(c, rec, text3, n, lcp, hugeStart, hugeLen);
     c->release(m);
 }
