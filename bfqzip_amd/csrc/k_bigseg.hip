@@ -135,12 +135,13 @@ static void huge_batch(bfq_ctx *c, SortRec rec, const u64 *text3, u16 *lcp, cons
     HIP_CHECK(hipMemcpyAsync(b.hoff, off.data(), 8ull * (nseg + 1), hipMemcpyHostToDevice, c->stream));
     KLAUNCH(c, K_HUGE_ROUND, 32.0 * (double)m, k_huge_expand, bfq_grid(m, 256), 256, (const u64 *)b.hstart, (const u64 *)b.hoff, nseg, m,
             rec, b.grow, b.gseg, b.pay);
+    u64 nsub = nseg;                                   // sub-segment ids are dense: 0 .. nsub-1
     for (u32 depth = BFQ_KEY_SYMS; m > 0; depth += BFQ_KEY_SYMS) {
         const unsigned g = bfq_grid(m, 256);
         KLAUNCH(c, K_HUGE_ROUND, 36.0 * (double)m, k_huge_keys, g, 256, (const u64 *)b.pay, text3, m, depth, b.K, b.R1);
         bfq_radix_sort(c, b.R1, b.R2, m);
         KLAUNCH(c, K_HUGE_ROUND, 28.0 * (double)m, k_huge_segkeys, g, 256, b.R1, (const u32 *)b.gseg, m, b.R2);
-        bfq_radix_sort(c, b.R2, b.R1, m, 4);
+        bfq_radix_sort(c, b.R2, b.R1, m, nsub <= (1ull << 16) ? 2 : 4);       // ids below 2^16: the two low digits are enough
         KLAUNCH(c, K_HUGE_ROUND, 44.0 * (double)m, k_huge_apply, g, 256, b.R2, (const u64 *)b.pay, (const u64 *)b.K, m, b.npay, b.nK);
         KLAUNCH(c, K_HUGE_ROUND, 44.0 * (double)m, k_huge_bounds, g, 256, (const u64 *)b.npay, (const u64 *)b.nK, (const u32 *)b.gseg,
                 (const u64 *)b.grow, m, depth, rec, lcp, b.cont, b.rhead);
@@ -148,10 +149,11 @@ static void huge_batch(bfq_ctx *c, SortRec rec, const u64 *text3, u16 *lcp, cons
         bfq_exscan_u8(c, b.rhead, b.hpos, m, b.tot + 1);
         KLAUNCH(c, K_HUGE_ROUND, 40.0 * (double)m, k_huge_compact, g, 256, (const u8 *)b.cont, (const u8 *)b.rhead, (const u64 *)b.cpos,
                 (const u64 *)b.hpos, (const u64 *)b.npay, (const u64 *)b.grow, m, b.grow2, b.gseg2, b.pay);
-        u64 left = 0;
-        HIP_CHECK(hipMemcpyAsync(&left, b.tot, 8, hipMemcpyDeviceToHost, c->stream));
+        u64 left[2] = {0, 0};                          // slots still tied, sub-segments they form
+        HIP_CHECK(hipMemcpyAsync(left, b.tot, 16, hipMemcpyDeviceToHost, c->stream));
         c->sync();
-        m = left;
+        m = left[0];
+        nsub = left[1];
         std::swap(b.grow, b.grow2);
         std::swap(b.gseg, b.gseg2);
         if (depth > BFQ_MAX_READ_LEN + 64) throw BfqError{BFQ_E_TOO_LONG, "suffix comparison ran past the longest read"};
