@@ -53,6 +53,14 @@ def test_parallel_cli_single_process(tmp_path):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
     assert hashlib.md5(open(out + ".fq", "rb").read()).hexdigest() == "4ada980195fd8d6fb206408c4f892bc6"
+    # --m3: the streams BFQzip.py cuts with sed -n 2~4p / 4~4p / 1~4p (BFQzip.py:19-21)
+    r = subprocess.run([sys.executable, "-m", "bfqzip_amd.parallel", fq, "-o", out, "-t", "8", "--m3"], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout.decode()[-2000:]
+    lines = open(out + ".fq", "rb").read().split(b"\n")[:-1]
+    assert open(out + ".fq.dna", "rb").read() == b"".join(x + b"\n" for x in lines[1::4])
+    assert open(out + ".fq.qs", "rb").read() == b"".join(x + b"\n" for x in lines[3::4])
+    assert open(out + ".h", "rb").read() == b"".join(x + b"\n" for x in open(fq, "rb").read().split(b"\n")[:-1][0::4])
     # paired: reads_1 / reads_2 of the reference's example = the two halves of the "paired" golden input
     from bfqzip_amd import fastq, parallel
     b, q, rr, h, *_ = util.golden_set("paired")
