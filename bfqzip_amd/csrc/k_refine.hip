@@ -59,8 +59,8 @@ __device__ __forceinline__ void wo_key2(const u64 *__restrict__ text3, u64 v, u3
 }
 
 __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restrict__ lcp, const u64 *__restrict__ text3,
-                                                      u64 n, u64 *__restrict__ biglist, DevCounters *cnt, u64 nchunks,
-                                                      u16 *__restrict__ firstHead)
+                                                      u64 n, u64 *__restrict__ biglist, u64 *__restrict__ biglen, DevCounters *cnt,
+                                                      u64 nchunks, u16 *__restrict__ firstHead)
 {
     // every wavefront works alone on its own chunk (no workgroup barriers): private LDS slices
     __shared__ u64 hb_all[4][RF_HBW];               // head bits of rows [base, base + RF_CHUNK + 256)
@@ -131,13 +131,15 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                 const u64 wd = hb[idx >> 6] >> (idx & 63);
                 u32 nxt;
                 if (wd) nxt = idx + (u32)__builtin_ctzll(wd);
-                else {
-                    const u64 w2 = hb[(idx >> 6) + 1];
-                    nxt = w2 ? (((idx >> 6) + 1) << 6) + (u32)__builtin_ctzll(w2) : 0xFFFFu;
+                else {                                             // head bits are valid up to the lookahead (RF_CHUNK + 128 rows)
+                    nxt = 0xFFFFu;
+                    for (u32 wi = (idx >> 6) + 1; wi < RF_CHUNK / 64 + 2; wi++) {
+                        const u64 w2 = hb[wi];
+                        if (w2) { nxt = (wi << 6) + (u32)__builtin_ctzll(w2); break; }
+                    }
                 }
-                u32 size = nxt - li;
-                if (size > 64) size = 0;                           // handled by k_refine_big
-                segs[o++] = li | (size << 16);
+                const u32 size = (nxt == 0xFFFFu) ? 0xFFFFu : nxt - li;      // 0xFFFF: ends beyond the lookahead
+                segs[o++] = li | (size << 16);                     // more than 64 rows: handled by k_refine_big
             }
             nsegs = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         }
@@ -149,7 +151,12 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
             u32 ent = (idx < nsegs) ? segs[idx] : 0u;
             u64 segStart = base + (ent & 0xFFFFu);
             u32 segSize = (idx < nsegs) ? (ent >> 16) : 0u;
-            if (idx < nsegs && segSize == 0) biglist[atomicAdd(&cnt->bigCount, 1ull)] = segStart;
+            if (segSize > 64) {                                    // listed with its length when that is known (0: to be searched)
+                const u64 k = atomicAdd(&cnt->bigCount, 1ull);
+                biglist[k] = segStart;
+                biglen[k] = (segSize == 0xFFFFu) ? 0ull : (u64)segSize;
+                segSize = 0;
+            }
             u32 incl = bfq_wave_incscan32(segSize);
             u32 excl = incl - segSize;
             u32 done = 0;
@@ -280,8 +287,9 @@ __device__ void big_sort(const SortRec &rec, u64 s, u64 g, const u64 *__restrict
 // over (sub-segment id, next word, original slot) kept in LDS: every row's next word is fetched once per
 // round, no suffix is compared through global memory.  Slot i of the segment is eBWT row s + i throughout, so
 // the LCP of a boundary is final the moment the boundary appears.
-// Three size classes: one wavefront (64 threads, no real barriers) for segments up to RB_SMALL rows, 128 threads up to
-// twice that, 256 threads up to BFQ_HUGE_SEG (one wavefront for the larger classes measured slower: LDS latency).
+// Five size classes, set by their LDS footprint (= how many run per CU): one wavefront (64 threads, no real barriers) for
+// segments up to 128, 256 and RB_SMALL rows, 128 threads up to twice that, 256 threads up to BFQ_HUGE_SEG (one wavefront
+// for the larger classes measured slower: LDS latency).
 #define RB_SMALL 512
 template <int PMAX> struct BlockSortLds {
     u64 W1[PMAX], W2[PMAX];   // next two words of the row now in slot i (0 for rows that are already alone)
@@ -392,7 +400,7 @@ __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restri
 // extent (kept in biglen) and sorts those of up to RB_SMALL rows; the 128- and 256-thread launches take the next
 // two size classes (their LDS footprint sets how many run per CU), the last one lists what is longer than
 // BFQ_HUGE_SEG rows for the radix rounds.
-template <int NT, int PMAX, bool FIRST>
+template <int NT, int PMIN, int PMAX, bool FIRST>
 __global__ __launch_bounds__(NT) void k_refine_big(const u64 *__restrict__ biglist, u64 *__restrict__ biglen, DevCounters *cnt, SortRec rec,
                                                    u16 *__restrict__ lcp, const u64 *__restrict__ text3, u64 n,
                                                    u64 *__restrict__ hugeStart, u64 *__restrict__ hugeLen,
@@ -404,7 +412,10 @@ __global__ __launch_bounds__(NT) void k_refine_big(const u64 *__restrict__ bigli
     for (u64 bi = blockIdx.x; bi < nbig; bi += gridDim.x) {
         const u64 s = biglist[bi];
         u64 g;
-        if (FIRST) {
+        if (FIRST && (g = biglen[bi]) != 0) {
+            if (g > PMAX) continue;                    // uniform; length known from the chunk kernel
+            grp_sync<NT>();
+        } else if (FIRST) {
             grp_sync<NT>();
             if (threadIdx.x == 0) shEnd = ~0ull;
             grp_sync<NT>();
@@ -441,7 +452,7 @@ __global__ __launch_bounds__(NT) void k_refine_big(const u64 *__restrict__ bigli
             if (g > PMAX) continue;                    // uniform
         } else {
             g = biglen[bi];
-            if (g <= PMAX / 2) continue;               // done by a smaller launch
+            if (g <= PMIN) continue;                   // done by a smaller launch
             if (g > BFQ_HUGE_SEG) {                    // uniform: left to the radix rounds
                 if (PMAX == BFQ_HUGE_SEG && threadIdx.x == 0) {
                     u64 h = atomicAdd(&cnt->hugeCount, 1ull);
@@ -514,17 +525,20 @@ void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_
     u16 *firstHead = c->alloc<u16>(nchunks + 1);
     // remaining packed suffix read once (3(L+1)/16 B) + order 8 B + LCP 1 B per row
     const double lavg = c->N ? (double)(n - c->N) / (double)c->N : 0.0;
+    u64 *biglen = c->alloc<u64>(n / 65 + 2);
     KLAUNCH(c, K_REFINE_WAVE, (3.0 * (lavg + 1.0) / 16.0 + 9.0) * (double)n, k_refine_chunk, bfq_grid(nchunks, 4), 256, rec, lcp, text3, n, biglist,
-            c->d_cnt, nchunks, firstHead);
+            biglen, c->d_cnt, nchunks, firstHead);
     u64 *hugeStart = c->alloc<u64>(n / BFQ_HUGE_SEG + 2), *hugeLen = c->alloc<u64>(n / BFQ_HUGE_SEG + 2);
     // the list length stays on the device: a fixed grid strides over it (usually empty)
-    u64 *biglen = c->alloc<u64>(n / 65 + 2);
-    KLAUNCH(c, K_REFINE_BIG, 0.0, (k_refine_big<64, RB_SMALL, true>), 4096, 64, (const u64 *)biglist, biglen, c->d_cnt, rec, lcp, text3, n,
-            hugeStart, hugeLen, (const u16 *)firstHead);
-    KLAUNCH(c, K_REFINE_BIG, 0.0, (k_refine_big<128, 2 * RB_SMALL, false>), 2048, 128, (const u64 *)biglist, biglen, c->d_cnt, rec, lcp, text3, n,
-            hugeStart, hugeLen, (const u16 *)firstHead);
-    KLAUNCH(c, K_REFINE_BIG, 0.0, (k_refine_big<256, BFQ_HUGE_SEG, false>), 1024, 256, (const u64 *)biglist, biglen, c->d_cnt, rec, lcp, text3, n,
-            hugeStart, hugeLen, (const u16 *)firstHead);
+#define RB_LAUNCH(NT, PMIN, PMAX, FIRST, GRID)                                                                              \
+    KLAUNCH(c, K_REFINE_BIG, 0.0, (k_refine_big<NT, PMIN, PMAX, FIRST>), GRID, NT, (const u64 *)biglist, biglen, c->d_cnt, rec, lcp, text3, n, \
+            hugeStart, hugeLen, (const u16 *)firstHead)
+    RB_LAUNCH(64, 64, 128, true, 8192);
+    RB_LAUNCH(64, 128, 256, false, 8192);
+    RB_LAUNCH(64, 256, RB_SMALL, false, 4096);
+    RB_LAUNCH(128, RB_SMALL, 2 * RB_SMALL, false, 2048);
+    RB_LAUNCH(256, 2 * RB_SMALL, BFQ_HUGE_SEG, false, 1024);
+#undef RB_LAUNCH
     bfq_refine_huge(c, rec, text3, n, lcp, hugeStart, hugeLen);
     c->release(m);
 }
