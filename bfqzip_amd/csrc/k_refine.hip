@@ -292,8 +292,8 @@ __device__ void big_sort(const SortRec &rec, u64 s, u64 g, const u64 *__restrict
 // for the larger classes measured slower: LDS latency).
 #define RB_SMALL 512
 template <int PMAX> struct BlockSortLds {
-    u64 W1[PMAX], W2[PMAX];   // next two words of the row now in slot i (0 for rows that are already alone)
-    u32 T[PMAX];          // sub-segment id << 12 | original slot (padding: all ones)
+    u64 W1[PMAX], W2[PMAX];   // by ORIGINAL slot: the row's next two words (0 for rows that are already alone)
+    u32 T[PMAX];          // by current slot: sub-segment id << 12 | original slot (padding: all ones); all the network moves
     u64 V[PMAX];          // by ORIGINAL slot: working form of the payload (word index / offset of p + 16)
     u32 scan[4];
     u32 open;
@@ -301,14 +301,6 @@ template <int PMAX> struct BlockSortLds {
 template <int NT> __device__ __forceinline__ void grp_sync()
 {
     if (NT == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
-}
-__device__ __forceinline__ bool rb_less(u32 ta, u64 a1, u64 a2, u32 tb, u64 b1, u64 b2)
-{
-    const u32 sa = ta >> 12, sb = tb >> 12;
-    if (sa != sb) return sa < sb;
-    if (a1 != b1) return a1 < b1;
-    if (a2 != b2) return a2 < b2;
-    return (ta & 0xFFFu) < (tb & 0xFFFu);
 }
 template <int NT, int PMAX>
 __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restrict__ text3, u16 *__restrict__ lcp, BlockSortLds<PMAX> &L)
@@ -318,7 +310,7 @@ __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restri
     while (P < g) P <<= 1;
     for (u32 i = tid; i < P; i += NT) {
         if (i < g) { L.V[i] = wo_from_pay(rec_pay(rec, s + i)); L.T[i] = i; }
-        else { L.T[i] = 0xFFFFFFFFu; L.W1[i] = ~0ull; L.W2[i] = ~0ull; }
+        else L.T[i] = 0xFFFFFFFFu;
     }
     grp_sync<NT>();
     u32 depth = BFQ_KEY_SYMS;
@@ -329,7 +321,7 @@ __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restri
             const bool alone = (i == 0 || (L.T[i - 1] >> 12) != sub) && (i + 1 >= g || (L.T[i + 1] >> 12) != sub);
             u64 w1 = 0, w2 = 0;
             if (!alone) wo_key2(text3, L.V[t & 0xFFFu], round, w1, w2);
-            L.W1[i] = w1; L.W2[i] = w2;
+            L.W1[t & 0xFFFu] = w1; L.W2[t & 0xFFFu] = w2;          // words stay with the original slot: the network moves T only
         }
         grp_sync<NT>();
         // bitonic network on (sub-segment, words, original slot); padding sorts last
@@ -339,10 +331,16 @@ __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restri
                     const u32 lo = ((c & ~(j - 1)) << 1) | (c & (j - 1)), hi = lo | j;
                     const bool up = (lo & k) == 0;
                     const u32 ta = L.T[lo], tb = L.T[hi];
-                    const u64 a1 = L.W1[lo], b1 = L.W1[hi], a2 = L.W2[lo], b2 = L.W2[hi];
-                    if (rb_less(tb, b1, b2, ta, a1, a2) == up) {
-                        L.T[lo] = tb; L.T[hi] = ta; L.W1[lo] = b1; L.W1[hi] = a1; L.W2[lo] = b2; L.W2[hi] = a2;
+                    bool less;                                     // (sub-segment, words, original slot) of hi < that of lo
+                    if ((ta >> 12) != (tb >> 12)) less = (tb >> 12) < (ta >> 12);
+                    else if (tb == 0xFFFFFFFFu) less = false;      // two padding slots
+                    else {
+                        const u32 ia = ta & 0xFFFu, ib = tb & 0xFFFu;
+                        const u64 a1 = L.W1[ia], b1 = L.W1[ib];
+                        if (a1 != b1) less = b1 < a1;
+                        else { const u64 a2 = L.W2[ia], b2 = L.W2[ib]; less = (a2 != b2) ? (b2 < a2) : (ib < ia); }
                     }
+                    if (less == up) { L.T[lo] = tb; L.T[hi] = ta; }
                 }
                 grp_sync<NT>();
             }
@@ -355,7 +353,7 @@ __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restri
             bool h = true;
             if (i) {
                 const u32 t = L.T[i], tp = L.T[i - 1];
-                const u64 w1 = L.W1[i], p1 = L.W1[i - 1], w2 = L.W2[i], p2 = L.W2[i - 1];
+                const u64 w1 = L.W1[t & 0xFFFu], p1 = L.W1[tp & 0xFFFu], w2 = L.W2[t & 0xFFFu], p2 = L.W2[tp & 0xFFFu];
                 const bool sameSub = (t >> 12) == (tp >> 12);
                 const bool d1 = w1 != p1 || bfq_key_has_term(w1);                  // decided by the first word
                 h = !sameSub || d1 || w2 != p2 || bfq_key_has_term(w2);
