@@ -2,8 +2,8 @@
 duplicates, the synthetic generator, homopolymers and tandem repeats, a few very long reads, tiny genomes at huge
 coverage, empty and one-base reads) under random parameters (-k -m -v -f -t, M 0-3, B 0-1).  Not collected by pytest:
     python tests/soak_gpu.py <seconds> <first seed>
-tests/test_gpu_parity.py::test_randomised_shapes_and_parameters runs the first cases of it.  Round 1: 27 380 cases /
-7.30 G rows in eight runs (one of them with BFQ_HUGE_CAP=20000, i.e. batching and the one-workgroup fallback of the
+tests/test_gpu_parity.py::test_randomised_shapes_and_parameters runs the first cases of it.  Round 1: 33 363 cases /
+8.96 G rows in nine runs (one of them with BFQ_HUGE_CAP=20000, i.e. batching and the one-workgroup fallback of the
 huge-segment rounds), all bit-exact (eBWT, permuted QS, LCP, output reads, statistics, bfq_int mode)."""
 import sys, time, numpy as np
 import os
