@@ -128,9 +128,11 @@ void bfq_exscan_u64(bfq_ctx *c, const u64 *in, u64 *out, u64 n, u64 *d_total);
 // step 1 pieces
 void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 n,
                     u8 *T8, u8 *Q8, u64 *text3, u64 nwords);
-void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out);
+// rows per radix workgroup (k_radix.hip); k_build_keys works on the same blocks to leave the first pass's digit counts
+#define BFQ_RS_BLOCK_ELEMS 98304
+void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0);   // hist0: [256][ceil(n / BFQ_RS_BLOCK_ELEMS)]
 // LSD radix sort of the records on their 48-bit key; result ends in A
-void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes = 6);   // passes even; fewer = low digits only
+void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes = 6, const u32 *hist0 = nullptr);   // passes even; fewer = low digits only; hist0: pass-0 counts already made
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
 void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
 // segments above BFQ_HUGE_SEG rows (listed by k_refine_big): whole-device radix rounds on the following symbols

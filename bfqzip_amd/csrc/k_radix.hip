@@ -23,6 +23,7 @@
 #define RS_TILE (RS_THREADS * RS_ROUNDS)            // 3072 records per tile
 #define RS_TILES_PER_BLOCK 32
 #define RS_BLOCK_ELEMS ((u64)RS_TILE * RS_TILES_PER_BLOCK)
+static_assert(RS_TILE * RS_TILES_PER_BLOCK == BFQ_RS_BLOCK_ELEMS, "k_build_keys counts the first digit per radix block");
 
 template <class T>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const T *__restrict__ dw, u64 n, int shift,
@@ -166,7 +167,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
 }
 
 // key48 digits: 0,1 in w1 (bits 16..31), 2..5 in w0.  6 passes (even): the result returns to A.
-void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes)
+void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes, const u32 *hist0)
 {
     if (n < 2) return;
     u64 nb = ceil_div(n, RS_BLOCK_ELEMS);
@@ -177,11 +178,13 @@ void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes)
     for (int pass = 0; pass < passes; pass++) {
         const int dw = pass < 2 ? 1 : 0;
         const int shift = pass < 2 ? 16 + 8 * pass : 8 * (pass - 2);
-        if (dw)
+        const bool have = (pass == 0 && hist0);            // made by k_build_keys
+        if (have) {}
+        else if (dw)
             KLAUNCH(c, K_RADIX_HIST, 8.0 * (double)n, k_radix_hist<u64>, nb, RS_THREADS, (const u64 *)in.w12, n, shift, hist, nb);
         else
             KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist<u32>, nb, RS_THREADS, (const u32 *)in.w0, n, shift, hist, nb);
-        bfq_exscan_u32(c, hist, off, 256 * nb, nullptr);
+        bfq_exscan_u32(c, have ? hist0 : hist, off, 256 * nb, nullptr);
         if (dw)
             KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb);
         else

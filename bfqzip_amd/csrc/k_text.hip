@@ -86,47 +86,61 @@ __global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n,
 // 12-byte records; the previous symbols / qualities arrive by one 4-byte load each, the records leave as
 // one 16-byte (w0) and two 16-byte (w12) stores
 __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, const u8 *__restrict__ Q8,
-                                                    const u64 *__restrict__ text3, u64 n, SortRec out)
+                                                    const u64 *__restrict__ text3, u64 n, SortRec out, u32 *__restrict__ hist0,
+                                                    u64 nblocks)
 {
-    // word index / symbol offset advance with the grid stride: one division per thread, not per row
-    const u64 stride = (u64)gridDim.x * blockDim.x * 4;
-    const u64 sw = stride / BFQ_SYMS_PER_WORD;
-    const u32 so = (u32)(stride - sw * BFQ_SYMS_PER_WORD);
-    u64 p0 = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    u64 w0 = p0 / BFQ_SYMS_PER_WORD;
-    u32 o0 = (u32)(p0 - w0 * BFQ_SYMS_PER_WORD);
-    for (; p0 < n; p0 += stride) {
-        u32 c4 = 0, q4 = 0;                                       // codes / qualities of text positions p0-1 .. p0+2
-        if (p0 >= 1 && p0 + 3 <= n) { c4 = *(const u32 *)(T8 + p0 - 1); q4 = *(const u32 *)(Q8 + p0 - 1); }
-        else for (int k = 0; k < 4; k++) { u64 t = p0 + k; if (t >= 1 && t - 1 < n) { c4 |= (u32)T8[t - 1] << (8 * k); q4 |= (u32)Q8[t - 1] << (8 * k); } }
-        u64 t0 = text3[w0], t1 = text3[w0 + 1], t2 = text3[w0 + 2];   // 4 windows span at most 3 words
-        u32 rw0[4];
-        u64 rw12[4];
-        u64 w = w0;
-        u32 o = o0;
+    // One workgroup per radix block (BFQ_RS_BLOCK_ELEMS consecutive rows), 1024 rows per sweep: the digit counts of
+    // the sort's first pass come out on the way (per-wave LDS histograms), which saves that pass's 8 B/row histogram read.
+    __shared__ u32 wh[4][256];
+    const u32 w = threadIdx.x >> 6;
+    // word index / symbol offset advance by 1024 rows per sweep: one division per block, not per row
+    const u32 sw = 1024 / BFQ_SYMS_PER_WORD, so = 1024 - sw * BFQ_SYMS_PER_WORD;
+    for (u64 hb = blockIdx.x; hb < nblocks; hb += gridDim.x) {
+        for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wh[0][0])[i] = 0;
+        __syncthreads();
+        const u64 bbase = hb * (u64)BFQ_RS_BLOCK_ELEMS;
+        u64 bend = bbase + BFQ_RS_BLOCK_ELEMS;
+        if (bend > n) bend = n;
+        u64 p0 = bbase + (u64)threadIdx.x * 4;
+        u64 w0 = p0 / BFQ_SYMS_PER_WORD;
+        u32 o0 = (u32)(p0 - w0 * BFQ_SYMS_PER_WORD);
+        for (; p0 < bend; p0 += 1024) {
+            u32 c4 = 0, q4 = 0;                                       // codes / qualities of text positions p0-1 .. p0+2
+            if (p0 >= 1 && p0 + 3 <= n) { c4 = *(const u32 *)(T8 + p0 - 1); q4 = *(const u32 *)(Q8 + p0 - 1); }
+            else for (int k = 0; k < 4; k++) { u64 t = p0 + k; if (t >= 1 && t - 1 < n) { c4 |= (u32)T8[t - 1] << (8 * k); q4 |= (u32)Q8[t - 1] << (8 * k); } }
+            u64 t0 = text3[w0], t1 = text3[w0 + 1], t2 = text3[w0 + 2];   // 4 windows span at most 3 words
+            u32 rw0[4];
+            u64 rw12[4];
+            u64 wd = w0;
+            u32 o = o0;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            u64 a = (w == w0) ? t0 : t1, bnext = (w == w0) ? t1 : t2;
-            u32 o3 = o * 3u;
-            u64 hi = (a << o3) & BFQ_M63;
-            u64 lo = o3 ? (bnext >> (63u - o3)) : 0ull;
-            u64 k48 = bfq_key48_of(bfq_mask_key(hi | lo));
-            u32 pc = (c4 >> (8 * k)) & 0xFFu;
-            u32 pq = pc ? (q4 >> (8 * k)) & 0xFFu : (u32)'#';
-            u64 pay = bfq_pack_val(p0 + k, pc, pq);
-            rw0[k] = bfq_rec_w0(k48);
-            rw12[k] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(k48, pay);
-            if (++o == BFQ_SYMS_PER_WORD) { o = 0; w++; }
+            for (int k = 0; k < 4; k++) {
+                u64 a = (wd == w0) ? t0 : t1, bnext = (wd == w0) ? t1 : t2;
+                u32 o3 = o * 3u;
+                u64 hi = (a << o3) & BFQ_M63;
+                u64 lo = o3 ? (bnext >> (63u - o3)) : 0ull;
+                u64 k48 = bfq_key48_of(bfq_mask_key(hi | lo));
+                u32 pc = (c4 >> (8 * k)) & 0xFFu;
+                u32 pq = pc ? (q4 >> (8 * k)) & 0xFFu : (u32)'#';
+                u64 pay = bfq_pack_val(p0 + k, pc, pq);
+                rw0[k] = bfq_rec_w0(k48);
+                rw12[k] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(k48, pay);
+                if (p0 + k < n) atomicAdd(&wh[w][(u32)k48 & 255u], 1u);   // digit 0 of the LSD sort = low byte of the key
+                if (++o == BFQ_SYMS_PER_WORD) { o = 0; wd++; }
+            }
+            if (p0 + 4 <= n) {
+                *(uint4 *)(out.w0 + p0) = make_uint4(rw0[0], rw0[1], rw0[2], rw0[3]);
+                *(ulonglong2 *)(out.w12 + p0) = make_ulonglong2(rw12[0], rw12[1]);
+                *(ulonglong2 *)(out.w12 + p0 + 2) = make_ulonglong2(rw12[2], rw12[3]);
+            } else {
+                for (int k = 0; p0 + k < n; k++) { out.w0[p0 + k] = rw0[k]; out.w12[p0 + k] = rw12[k]; }
+            }
+            w0 += sw; o0 += so;
+            if (o0 >= BFQ_SYMS_PER_WORD) { o0 -= BFQ_SYMS_PER_WORD; w0++; }
         }
-        if (p0 + 4 <= n) {
-            *(uint4 *)(out.w0 + p0) = make_uint4(rw0[0], rw0[1], rw0[2], rw0[3]);
-            *(ulonglong2 *)(out.w12 + p0) = make_ulonglong2(rw12[0], rw12[1]);
-            *(ulonglong2 *)(out.w12 + p0 + 2) = make_ulonglong2(rw12[2], rw12[3]);
-        } else {
-            for (int k = 0; p0 + k < n; k++) { out.w0[p0 + k] = rw0[k]; out.w12[p0 + k] = rw12[k]; }
-        }
-        w0 += sw; o0 += so;
-        if (o0 >= BFQ_SYMS_PER_WORD) { o0 -= BFQ_SYMS_PER_WORD; w0++; }
+        __syncthreads();
+        hist0[(u64)threadIdx.x * nblocks + hb] = wh[0][threadIdx.x] + wh[1][threadIdx.x] + wh[2][threadIdx.x] + wh[3][threadIdx.x];
+        __syncthreads();
     }
 }
 
@@ -142,8 +156,10 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
             nwords);
 }
 
-void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out)
+
+void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0)
 {
     if (!n) return;
-    KLAUNCH(c, K_KEYS, 14.5 * (double)n, k_build_keys, bfq_grid((n + 3) / 4, 256), 256, T8, Q8, text3, n, out);
+    const u64 nb = ceil_div(n, BFQ_RS_BLOCK_ELEMS);
+    KLAUNCH(c, K_KEYS, 14.5 * (double)n, k_build_keys, bfq_grid(nb, 1), 256, T8, Q8, text3, n, out, hist0, nb);
 }
