@@ -16,7 +16,8 @@ SYMBOLS = [
     "bfq_last_error", "bfq_stream", "bfq_device_count", "bfq_build_ebwt", "bfq_count_reads",
     "bfq_smooth_invert", "bfq_run_reads", "bfq_run_reads_device", "bfq_fetch_ebwt",
     "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_fastq_run_streams",
-    "bfq_smooth_invert_fastq",
+    "bfq_smooth_invert_fastq", "bfq_fastq_run_job", "bfq_host_alloc", "bfq_host_free",
+    "bfq_text_count_lines", "bfq_text_nth_newline",
     "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device",
     "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
     "bfq_workspace_bytes", "bfq_version",
@@ -43,6 +44,24 @@ class Synth(C.Structure):
                 ("coverage", C.c_uint32), ("err_ppm", C.c_uint32), ("n_ppm", C.c_uint32),
                 ("snp_every", C.c_uint32), ("dsnp_every", C.c_uint32), ("both_strands", C.c_uint32),
                 ("reserved", C.c_uint32 * 5)]
+
+
+MAX_PARTS = 4
+
+
+class TextPart(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("len", C.c_uint64)]
+
+
+class FastqJob(C.Structure):
+    _fields_ = [("parts", C.POINTER(TextPart)), ("nparts", C.c_int32), ("keep_headers", C.c_int32),
+                ("out_fastq", C.c_void_p), ("cap_fastq", C.c_uint64),
+                ("out_dna", C.c_void_p), ("out_qs", C.c_void_p), ("cap_stream", C.c_uint64),
+                ("out_hdr", C.c_void_p), ("cap_hdr", C.c_uint64),
+                ("fastq_len", C.c_uint64), ("stream_len", C.c_uint64), ("hdr_len", C.c_uint64),
+                ("n_reads", C.c_uint64), ("total_bases", C.c_uint64),
+                ("part_reads", C.c_uint64 * (MAX_PARTS + 1)), ("part_fastq_off", C.c_uint64 * (MAX_PARTS + 1)),
+                ("part_stream_off", C.c_uint64 * (MAX_PARTS + 1)), ("part_hdr_off", C.c_uint64 * (MAX_PARTS + 1))]
 
 
 def build(clean=False):
@@ -94,6 +113,13 @@ def lib():
                                             C.POINTER(Stats)]
         L.bfq_smooth_invert_fastq.argtypes = [vp, vp, vp, vp, C.c_int, u64, vp, u64, vp, u64, C.POINTER(u64),
                                               C.POINTER(Stats)]
+        L.bfq_fastq_run_job.argtypes = [vp, C.POINTER(FastqJob), C.POINTER(Stats)]
+        L.bfq_host_alloc.restype = vp
+        L.bfq_host_alloc.argtypes = [u64]
+        L.bfq_host_free.argtypes = [vp]
+        L.bfq_text_count_lines.argtypes = [vp, u64, u64, vp, C.c_int]
+        L.bfq_text_nth_newline.restype = C.c_int64
+        L.bfq_text_nth_newline.argtypes = [vp, u64, u64]
         L.bfq_synth_default.argtypes = [C.POINTER(Synth), u64, C.c_uint32]
         L.bfq_synth_total.argtypes = [C.POINTER(Synth)]
         L.bfq_synth_host.argtypes = [C.POINTER(Synth), vp, vp, vp]

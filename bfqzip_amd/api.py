@@ -35,8 +35,64 @@ def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
 
 
+def _u8(text):
+    """bytes / bytearray / ndarray / memmap slice -> contiguous uint8 ndarray (no copy when possible)."""
+    if isinstance(text, np.ndarray):
+        return text if (text.dtype == np.uint8 and text.flags.c_contiguous) else np.ascontiguousarray(text, np.uint8)
+    return np.frombuffer(text, np.uint8)
+
+
+class PinnedBuffer:
+    """Page-locked host memory (bfq_host_alloc) as a uint8 numpy array: transferred by direct DMA."""
+
+    def __init__(self, nbytes):
+        self.L = _lib.lib()
+        self.nbytes = int(nbytes)
+        self.ptr = self.L.bfq_host_alloc(max(self.nbytes, 1))
+        if not self.ptr:
+            raise MemoryError(f"bfq_host_alloc({nbytes})")
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(self.nbytes, 1)).from_address(self.ptr))[:self.nbytes]
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.L.bfq_host_free(self.ptr)
+            self.ptr = None
+
+    __del__ = free
+
+
+class JobResult:
+    """Outputs of Engine.fastq_job: arrays trimmed to their lengths + where every input part's share starts."""
+    __slots__ = ("fastq", "dna", "qs", "hdr", "n_reads", "total_bases", "part_reads", "part_fastq_off",
+                 "part_stream_off", "part_hdr_off", "stats")
+
+
+def text_line_counts(buf, chunk=1 << 20, threads=0):
+    """Number of newlines in every `chunk` bytes of a text (host threads, no GPU): uint64 array."""
+    a = _u8(buf)
+    nch = (len(a) + chunk - 1) // chunk
+    counts = np.zeros(max(nch, 1), np.uint64)
+    rc = _lib.lib().bfq_text_count_lines(_ptr(a) if len(a) else None, len(a), chunk, _ptr(counts), threads)
+    if rc:
+        raise BfqError(rc, "bfq_text_count_lines")
+    return counts[:nch]
+
+
+def text_nth_newline(buf, k):
+    a = _u8(buf)
+    return int(_lib.lib().bfq_text_nth_newline(_ptr(a) if len(a) else None, len(a), k))
+
+
+class HostText:
+    """Host-side text helpers of libbfqhip.so (no GPU involved)."""
+    text_line_counts = staticmethod(text_line_counts)
+    text_nth_newline = staticmethod(text_nth_newline)
+
+
 class Engine:
     """One GPU context (one stream, one device workspace). Not thread-safe."""
+    host = HostText
 
     def __init__(self, device=0, **params):
         self.L = _lib.lib()
@@ -142,6 +198,53 @@ class Engine:
                                               _ptr(hdr) if want_headers else None, cap, C.byref(hl), C.byref(st)))
         return (dna[:sl.value].tobytes(), qs[:sl.value].tobytes(),
                 hdr[:hl.value].tobytes() if want_headers else None, st.as_dict())
+
+    def fastq_job(self, parts, keep_headers=False, fastq=True, streams=False, hdr=False, out=None):
+        """One block of BFQzip_parallel.py in one call (bfq_fastq_run_job): `parts` = 1..4 byte ranges (bytes,
+        uint8 arrays, memmap slices) processed as one collection; outputs as asked: the FASTQ text, the --m2
+        streams (dna, qs), the --m3 header stream.  `out` may give reusable output arrays (e.g. PinnedBuffer.array)
+        under the keys 'fastq', 'dna', 'qs', 'hdr'."""
+        arrs = [_u8(p) for p in parts]
+        np_ = len(arrs)
+        tp = (_lib.TextPart * np_)()
+        for i, a in enumerate(arrs):
+            tp[i].data = a.ctypes.data if len(a) else None
+            tp[i].len = len(a)
+        inlen = sum(len(a) for a in arrs)
+        out = out or {}
+
+        def buf(key, want, size):
+            if not want:
+                return None
+            b = out.get(key)
+            if b is None or len(b) < size:
+                b = np.empty(size, np.uint8)
+            return b
+        J = _lib.FastqJob()
+        J.parts = tp; J.nparts = np_; J.keep_headers = 1 if keep_headers else 0
+        bf = buf("fastq", fastq, inlen + 5 * np_ + 16)
+        bd, bq = buf("dna", streams, inlen + 16), buf("qs", streams, inlen + 16)
+        bh = buf("hdr", hdr, inlen + 16)
+        if bf is not None:
+            J.out_fastq = bf.ctypes.data; J.cap_fastq = len(bf)
+        if bd is not None:
+            J.out_dna = bd.ctypes.data; J.out_qs = bq.ctypes.data; J.cap_stream = min(len(bd), len(bq))
+        if bh is not None:
+            J.out_hdr = bh.ctypes.data; J.cap_hdr = len(bh)
+        st = _lib.Stats()
+        self._ck(self.L.bfq_fastq_run_job(self.h, C.byref(J), C.byref(st)))
+        r = JobResult()
+        r.fastq = bf[:J.fastq_len] if bf is not None else None
+        r.dna = bd[:J.stream_len] if bd is not None else None
+        r.qs = bq[:J.stream_len] if bq is not None else None
+        r.hdr = bh[:J.hdr_len] if bh is not None else None
+        r.n_reads, r.total_bases = int(J.n_reads), int(J.total_bases)
+        r.part_reads = [int(J.part_reads[i]) for i in range(np_ + 1)]
+        r.part_fastq_off = [int(J.part_fastq_off[i]) for i in range(np_ + 1)]
+        r.part_stream_off = [int(J.part_stream_off[i]) for i in range(np_ + 1)]
+        r.part_hdr_off = [int(J.part_hdr_off[i]) for i in range(np_ + 1)]
+        r.stats = st.as_dict()
+        return r
 
     def smooth_invert_fastq(self, bwt, qs, lcp=None, headers=None):
         """bfq_int / bfq_ext writing the FASTQ text; headers = bytes of the -H file or None."""

@@ -157,6 +157,8 @@ extern "C" void bfq_destroy(bfq_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto e : c->evPool) (void)hipEventDestroy(e);
+    c->ioFree();
+    if (c->d_text) (void)hipFree(c->d_text);
     if (c->ws) (void)hipFree(c->ws);
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->d_powtab) (void)hipFree(c->d_powtab);
@@ -320,13 +322,13 @@ extern "C" int bfq_run_reads(bfq_ctx *c, const uint8_t *h_bases, const uint8_t *
         u8 *db = c->alloc<u8>(total + 64), *dq = c->alloc<u8>(total + 64);
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
         u64 *dr = c->alloc<u64>(N + 1);
-        HIP_CHECK(hipMemcpyAsync(db, h_bases, total, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(dq, h_quals, total, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(dr, h_read_off, 8 * (N + 1), hipMemcpyHostToDevice, c->stream));
+        bfq_upload(c, db, h_bases, total);
+        bfq_upload(c, dq, h_quals, total);
+        bfq_upload(c, dr, h_read_off, 8 * (N + 1));
         bfq_step1_device(c, db, dq, dr, N, total, c->P.term, st);
         steps234_device(c, dr, ob, oq);
-        HIP_CHECK(hipMemcpyAsync(h_out_bases, ob, total, hipMemcpyDeviceToHost, c->stream));
-        HIP_CHECK(hipMemcpyAsync(h_out_quals, oq, total, hipMemcpyDeviceToHost, c->stream));
+        bfq_download(c, h_out_bases, ob, total);
+        bfq_download(c, h_out_quals, oq, total);
         c->fetchCounters();
         c->profCollect();
         check_counters(c);
@@ -344,13 +346,13 @@ extern "C" int bfq_build_ebwt(bfq_ctx *c, const uint8_t *h_bases, const uint8_t 
         c->zeroCounters();
         u8 *db = c->alloc<u8>(total + 64), *dq = c->alloc<u8>(total + 64);
         u64 *dr = c->alloc<u64>(N + 1);
-        HIP_CHECK(hipMemcpyAsync(db, h_bases, total, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(dq, h_quals, total, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(dr, h_read_off, 8 * (N + 1), hipMemcpyHostToDevice, c->stream));
+        bfq_upload(c, db, h_bases, total);
+        bfq_upload(c, dq, h_quals, total);
+        bfq_upload(c, dr, h_read_off, 8 * (N + 1));
         bfq_step1_device(c, db, dq, dr, N, total, term_out, nullptr);
-        if (h_bwt) HIP_CHECK(hipMemcpyAsync(h_bwt, c->d_bwt, n, hipMemcpyDeviceToHost, c->stream));
-        if (h_bwtqs) HIP_CHECK(hipMemcpyAsync(h_bwtqs, c->d_qual, n, hipMemcpyDeviceToHost, c->stream));
-        if (h_lcp16) HIP_CHECK(hipMemcpyAsync(h_lcp16, c->d_lcp, 2 * n, hipMemcpyDeviceToHost, c->stream));
+        if (h_bwt) bfq_download(c, h_bwt, c->d_bwt, n);
+        if (h_bwtqs) bfq_download(c, h_bwtqs, c->d_qual, n);
+        if (h_lcp16) bfq_download(c, h_lcp16, c->d_lcp, 2 * n);
         c->fetchCounters();
         c->profCollect();
         check_counters(c);
@@ -368,13 +370,12 @@ extern "C" int bfq_fetch_ebwt(bfq_ctx *c, uint8_t *h_bwt, uint8_t *h_qs, uint16_
     });
 }
 
-extern "C" int bfq_count_reads(const uint8_t *h_bwt, uint64_t n, int term, uint64_t *N)
+__global__ __launch_bounds__(256) void k_lcp_widen(const u8 *__restrict__ raw, int lb, u64 n, u16 *__restrict__ out)
 {
-    if (!N || (n && !h_bwt)) return BFQ_E_ARG;
-    u64 k = 0;
-    for (u64 i = 0; i < n; i++) k += (h_bwt[i] == (u8)term);
-    *N = k;
-    return BFQ_OK;
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        u64 v = lb == 1 ? raw[i] : lb == 2 ? ((const u16 *)raw)[i] : ((const u32 *)raw)[i];
+        out[i] = (u16)(v > 0xFFFE ? 0xFFFE : v);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_compare_bytes(const u8 *__restrict__ a, const u8 *__restrict__ b, u64 n,
@@ -399,26 +400,26 @@ static void smooth_invert_core(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *
         u64 N = Nr;
         if (n && N == 0) throw BfqError{BFQ_E_NOT_EBWT, "no terminator in the eBWT"};
         u64 total = n - N;
-        c->reserve(ws_need(n, N, 6 * (n + 256) + 16 * (N + 64) + extraWs));
+        c->reserve(ws_need(n, N, 10 * (n + 256) + 16 * (N + 64) + extraWs));
         c->zeroCounters();
         u8 *in_bwt = c->alloc<u8>(n + 64), *in_qs = c->alloc<u8>(n + 64);
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
         u64 *d_roff = c->alloc<u64>(N + 1);
         u32 *lens = c->alloc<u32>(N + 1);
-        HIP_CHECK(hipMemcpyAsync(in_bwt, h_bwt, n, hipMemcpyHostToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(in_qs, h_bwtqs, n, hipMemcpyHostToDevice, c->stream));
-        std::vector<u16> lcp16;
+        bfq_upload(c, in_bwt, h_bwt, n);
+        bfq_upload(c, in_qs, h_bwtqs, n);
         if (h_lcp) {
             // explicit LCP (bfq_ext): persistent arrays hold the given eBWT directly
             c->n = n; c->N = N;
             c->d_bwt = in_bwt; c->d_qual = in_qs;
             c->d_lcp = c->alloc<u16>(n + 64);
-            lcp16.resize(n);
-            for (u64 i = 0; i < n; i++) {
-                u64 v = lcp_bytes == 1 ? ((const u8 *)h_lcp)[i] : lcp_bytes == 2 ? ((const u16 *)h_lcp)[i] : ((const u32 *)h_lcp)[i];
-                lcp16[i] = (u16)(v > 0xFFFE ? 0xFFFE : v);
+            {   // the file's entries (1, 2 or 4 bytes) are widened / clamped to 16 bits on the device
+                size_t mr = c->mark();
+                u8 *raw = c->alloc<u8>((size_t)lcp_bytes * n + 64);
+                bfq_upload(c, raw, h_lcp, (size_t)lcp_bytes * n);
+                KLAUNCH(c, K_MISC, (double)(lcp_bytes + 2) * (double)n, k_lcp_widen, bfq_grid(n, 256), 256, (const u8 *)raw, lcp_bytes, n, c->d_lcp);
+                c->release(mr);
             }
-            HIP_CHECK(hipMemcpyAsync(c->d_lcp, lcp16.data(), 2 * n, hipMemcpyHostToDevice, c->stream));
             size_t m = c->mark();
             RankIndex R0 = bfq_rank_build(c, in_bwt, in_qs, n, c->P.term);
             bfq_invert_count(c, R0, N, lens);
@@ -460,11 +461,9 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
     return guarded(c, [&] {
         SmoothOut r;
         smooth_invert_core(c, h_bwt, h_bwtqs, h_lcp, lcp_bytes, n, 0, st, &r);
-        if (r.total) {
-            HIP_CHECK(hipMemcpyAsync(h_out_bases, r.ob, r.total, hipMemcpyDeviceToHost, c->stream));
-            HIP_CHECK(hipMemcpyAsync(h_out_quals, r.oq, r.total, hipMemcpyDeviceToHost, c->stream));
-        }
-        HIP_CHECK(hipMemcpyAsync(h_out_read_off, r.roff, 8 * (r.N + 1), hipMemcpyDeviceToHost, c->stream));
+        bfq_download(c, h_out_bases, r.ob, r.total);
+        bfq_download(c, h_out_quals, r.oq, r.total);
+        bfq_download(c, h_out_read_off, r.roff, 8 * (r.N + 1));
         c->fetchCounters();
         c->profCollect();
         check_counters(c);
@@ -473,22 +472,49 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
 }
 
 // ---------------------------------------------------------------- FASTQ text in / out
-// The FASTQ text lives outside the arena (its record count sizes the arena): uploaded first, lines
-// counted on the device, then the workspace is reserved for the real N.
-struct DevText {
-    u8 *p = nullptr;
-    ~DevText() { if (p) (void)hipFree(p); }
-};
+// The FASTQ text lives outside the arena (its record count sizes the arena) in a buffer the context keeps
+// between calls: uploaded first, lines counted on the device, then the workspace is reserved for the real N.
 u64 bfq_fastq_count_lines(bfq_ctx *c, const u8 *d_buf, u64 len);   // k_fastq.hip
-static void fastq_upload_and_reserve(bfq_ctx *c, const uint8_t *h_fastq, u64 len, DevText &t)
+u8 *bfq_ctx::textBuf(size_t bytes)
 {
-    if (hipMalloc((void **)&t.p, len + 64) != hipSuccess) { (void)hipGetLastError(); t.p = nullptr; throw BfqError{BFQ_E_NOMEM, "device buffer for the FASTQ text"}; }
-    if (len) HIP_CHECK(hipMemcpyAsync(t.p, h_fastq, len, hipMemcpyHostToDevice, c->stream));
+    if (bytes > textCap) {
+        if (d_text) { HIP_CHECK(hipStreamSynchronize(stream)); HIP_CHECK(hipFree(d_text)); d_text = nullptr; textCap = 0; }
+        size_t want = (bytes + (bytes >> 4) + 0xFFFFF) & ~(size_t)0xFFFFF;
+        if (hipMalloc((void **)&d_text, want) != hipSuccess) {
+            (void)hipGetLastError();
+            d_text = nullptr;
+            throw BfqError{BFQ_E_NOMEM, "device buffer for the FASTQ text"};
+        }
+        textCap = want;
+    }
+    return d_text;
+}
+
+// Uploads the parts back to back (a part that does not end in '\n' gets one, so that no record straddles two
+// parts); pstart[p] = offset of part p in the device text, pstart[nparts] = its length.
+static u8 *fastq_upload_and_reserve(bfq_ctx *c, const bfq_text_part *parts, int nparts, std::vector<u64> &pstart)
+{
+    pstart.assign(nparts + 1, 0);
+    std::vector<u8> addNl(nparts, 0);
+    u64 len = 0;
+    for (int p = 0; p < nparts; p++) {
+        if (parts[p].len && !parts[p].data) throw BfqError{BFQ_E_ARG, "null FASTQ text"};
+        pstart[p] = len;
+        len += parts[p].len;
+        if (parts[p].len && parts[p].data[parts[p].len - 1] != (u8)'\n') { addNl[p] = 1; len++; }
+    }
+    pstart[nparts] = len;
+    u8 *d_fq = c->textBuf(len + 64);
+    for (int p = 0; p < nparts; p++) {
+        bfq_upload(c, d_fq + pstart[p], parts[p].data, parts[p].len);
+        if (addNl[p]) HIP_CHECK(hipMemsetAsync(d_fq + pstart[p] + parts[p].len, '\n', 1, c->stream));
+    }
     c->reserve(16 * (len / 4096 + 16) + (64u << 20));
-    u64 nlines = bfq_fastq_count_lines(c, t.p, len);
+    u64 nlines = bfq_fastq_count_lines(c, d_fq, len);
     u64 N = nlines / 4 + 1;
     u64 nb = len / 2 + 1;                                       // rows <= bytes / 2
     c->reserve(ws_need(nb, N, 3 * (len + 4096) + 128 * (N + 64) + 8 * (nlines + 64)));
+    return d_fq;
 }
 
 extern "C" uint64_t bfq_fastq_out_bound(uint64_t total_bases, uint64_t n_reads, uint64_t header_bytes)
@@ -501,85 +527,122 @@ extern "C" int bfq_fastq_build_ebwt(bfq_ctx *c, const uint8_t *h_fastq, uint64_t
                                     uint64_t *n_reads)
 {
     return guarded(c, [&] {
-        DevText txt;
-        fastq_upload_and_reserve(c, h_fastq, len, txt);
+        bfq_text_part part{h_fastq, len};
+        std::vector<u64> ps;
+        u8 *d_fq = fastq_upload_and_reserve(c, &part, 1, ps);
         c->zeroCounters();
-        u8 *d_fq = txt.p;
         DevFastq fq;
-        bfq_fastq_parse(c, d_fq, len, &fq);
+        bfq_fastq_parse(c, d_fq, ps[1], &fq);
         u64 n = fq.total + fq.N;
         if (n_rows) *n_rows = n;
         if (n_reads) *n_reads = fq.N;
         if (n > cap_rows) throw BfqError{BFQ_E_ARG, "output buffers smaller than the eBWT (need total bases + reads entries)"};
         bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, term_out, nullptr);
-        if (h_bwt) HIP_CHECK(hipMemcpyAsync(h_bwt, c->d_bwt, n, hipMemcpyDeviceToHost, c->stream));
-        if (h_bwtqs) HIP_CHECK(hipMemcpyAsync(h_bwtqs, c->d_qual, n, hipMemcpyDeviceToHost, c->stream));
-        if (h_lcp16) HIP_CHECK(hipMemcpyAsync(h_lcp16, c->d_lcp, 2 * n, hipMemcpyDeviceToHost, c->stream));
+        if (h_bwt) bfq_download(c, h_bwt, c->d_bwt, n);
+        if (h_bwtqs) bfq_download(c, h_bwtqs, c->d_qual, n);
+        if (h_lcp16) bfq_download(c, h_lcp16, c->d_lcp, 2 * n);
         c->fetchCounters();
         c->profCollect();
         check_counters(c);
+    });
+}
+
+void bfq_fastq_part_index(bfq_ctx *c, const DevFastq *fq, const u64 *h_pstart, int nparts, u64 *d_idx);   // k_fastq.hip
+void bfq_pick_u64(bfq_ctx *c, const u64 *d_src, const u64 *d_idx, int count, u64 addIdx, u64 *d_out);      // k_fastq.hip
+
+extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        if (st) memset(st, 0, sizeof *st);
+        if (!J || J->nparts < 1 || J->nparts > BFQ_MAX_PARTS || !J->parts) throw BfqError{BFQ_E_ARG, "bfq_fastq_job: 1..BFQ_MAX_PARTS parts"};
+        const int np = J->nparts;
+        J->fastq_len = J->stream_len = J->hdr_len = J->n_reads = J->total_bases = 0;
+        std::vector<u64> ps;
+        u8 *d_fq = fastq_upload_and_reserve(c, J->parts, np, ps);
+        const u64 len = ps[np];
+        c->zeroCounters();
+        DevFastq fq;
+        bfq_fastq_parse(c, d_fq, len, &fq);
+        J->n_reads = fq.N; J->total_bases = fq.total;
+        u8 *ob = c->alloc<u8>(fq.total + 64), *oq = c->alloc<u8>(fq.total + 64);
+        // per part: index of its first record, and where its share of every output starts (np + 1 entries each)
+        u64 *d_pidx = c->alloc<u64>(np + 1), *d_pick = c->alloc<u64>(4 * (np + 1));
+        bfq_fastq_part_index(c, &fq, ps.data(), np, d_pidx);
+        size_t m = c->mark();
+        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
+        steps234_device(c, fq.roff, ob, oq);
+        c->release(m);                                         // the formatted text may reuse the pipeline's space
+        std::vector<u64> hp(4 * (np + 1), 0);
+        bool pickF = false, pickS = false, pickH = false;
+        HIP_CHECK(hipMemcpyAsync(hp.data(), d_pidx, 8 * (np + 1), hipMemcpyDeviceToHost, c->stream));
+        if (J->out_fastq) {
+            u8 *d_out = nullptr;
+            u64 *recOff = nullptr;
+            u64 ol = bfq_fastq_format(c, ob, oq, fq.roff, fq.N, J->keep_headers ? 2 : 0, d_fq, len, &fq, &d_out, &recOff);
+            J->fastq_len = ol;
+            if (ol > J->cap_fastq) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
+            bfq_download(c, J->out_fastq, d_out, ol);
+            bfq_pick_u64(c, recOff, d_pidx, np + 1, 0, d_pick + (np + 1));
+            pickF = true;
+        }
+        if (J->out_dna || J->out_qs || J->out_hdr) {
+            u8 *d_dna = nullptr, *d_qs = nullptr, *d_hdr = nullptr;
+            u64 *hOff = nullptr;
+            u64 hl = 0, sl = fq.total + fq.N;
+            bfq_fastq_streams(c, ob, oq, fq.roff, fq.N, fq.total, d_fq, &fq, &d_dna, &d_qs, J->out_hdr ? &d_hdr : nullptr, &hl, &hOff);
+            J->stream_len = sl; J->hdr_len = hl;
+            if (((J->out_dna || J->out_qs) && sl > J->cap_stream) || (J->out_hdr && hl > J->cap_hdr))
+                throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
+            if (J->out_dna) bfq_download(c, J->out_dna, d_dna, sl);
+            if (J->out_qs) bfq_download(c, J->out_qs, d_qs, sl);
+            if (J->out_hdr) bfq_download(c, J->out_hdr, d_hdr, hl);
+            bfq_pick_u64(c, fq.roff, d_pidx, np + 1, 1, d_pick + 2 * (np + 1));           // roff[i] + i
+            pickS = true;
+            if (J->out_hdr) { bfq_pick_u64(c, hOff, d_pidx, np + 1, 0, d_pick + 3 * (np + 1)); pickH = true; }
+        }
+        HIP_CHECK(hipMemcpyAsync(hp.data() + (np + 1), d_pick + (np + 1), 8 * 3 * (np + 1), hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        c->profCollect();
+        check_counters(c);
+        fill_stats(c, st);
+        for (int p = 0; p <= np; p++) {
+            J->part_reads[p] = hp[p];
+            J->part_fastq_off[p] = pickF ? hp[(np + 1) + p] : 0;
+            J->part_stream_off[p] = pickS ? hp[2 * (np + 1) + p] : 0;
+            J->part_hdr_off[p] = pickH ? hp[3 * (np + 1) + p] : 0;
+        }
     });
 }
 
 extern "C" int bfq_fastq_run(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int keep_headers, uint8_t *h_out,
                              uint64_t cap, uint64_t *out_len, bfq_stats *st)
 {
-    return guarded(c, [&] {
-        if (st) memset(st, 0, sizeof *st);
-        DevText txt;
-        fastq_upload_and_reserve(c, h_fastq, len, txt);
-        c->zeroCounters();
-        u8 *d_fq = txt.p;
-        DevFastq fq;
-        bfq_fastq_parse(c, d_fq, len, &fq);
-        u8 *ob = c->alloc<u8>(fq.total + 64), *oq = c->alloc<u8>(fq.total + 64);
-        size_t m = c->mark();
-        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
-        steps234_device(c, fq.roff, ob, oq);
-        c->release(m);                                         // the formatted text may reuse the pipeline's space
-        u8 *d_out = nullptr;
-        u64 ol = bfq_fastq_format(c, ob, oq, fq.roff, fq.N, keep_headers ? 2 : 0, d_fq, len, &fq, &d_out);
-        if (out_len) *out_len = ol;
-        if (ol > cap) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
-        if (ol) HIP_CHECK(hipMemcpyAsync(h_out, d_out, ol, hipMemcpyDeviceToHost, c->stream));
-        c->fetchCounters();
-        c->profCollect();
-        check_counters(c);
-        fill_stats(c, st);
-    });
+    bfq_text_part part{h_fastq, len};
+    bfq_fastq_job J;
+    memset(&J, 0, sizeof J);
+    J.parts = &part; J.nparts = 1; J.keep_headers = keep_headers;
+    J.out_fastq = h_out; J.cap_fastq = cap;
+    if (!h_out) return BFQ_E_ARG;
+    int rc = bfq_fastq_run_job(c, &J, st);
+    if (out_len) *out_len = J.fastq_len;
+    return rc;
 }
 
 extern "C" int bfq_fastq_run_streams(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, uint8_t *h_dna, uint8_t *h_qs,
                                      uint64_t cap_stream, uint64_t *stream_len, uint8_t *h_hdr, uint64_t cap_hdr,
                                      uint64_t *hdr_len, bfq_stats *st)
 {
-    return guarded(c, [&] {
-        if (st) memset(st, 0, sizeof *st);
-        DevText txt;
-        fastq_upload_and_reserve(c, h_fastq, len, txt);
-        c->zeroCounters();
-        u8 *d_fq = txt.p;
-        DevFastq fq;
-        bfq_fastq_parse(c, d_fq, len, &fq);
-        u8 *ob = c->alloc<u8>(fq.total + 64), *oq = c->alloc<u8>(fq.total + 64);
-        size_t m = c->mark();
-        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
-        steps234_device(c, fq.roff, ob, oq);
-        c->release(m);
-        u8 *d_dna = nullptr, *d_qs = nullptr, *d_hdr = nullptr;
-        u64 hl = 0, sl = fq.total + fq.N;
-        bfq_fastq_streams(c, ob, oq, fq.roff, fq.N, fq.total, d_fq, &fq, &d_dna, &d_qs, h_hdr ? &d_hdr : nullptr, &hl);
-        if (stream_len) *stream_len = sl;
-        if (hdr_len) *hdr_len = hl;
-        if (sl > cap_stream || (h_hdr && hl > cap_hdr)) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
-        if (sl && h_dna) HIP_CHECK(hipMemcpyAsync(h_dna, d_dna, sl, hipMemcpyDeviceToHost, c->stream));
-        if (sl && h_qs) HIP_CHECK(hipMemcpyAsync(h_qs, d_qs, sl, hipMemcpyDeviceToHost, c->stream));
-        if (hl && h_hdr) HIP_CHECK(hipMemcpyAsync(h_hdr, d_hdr, hl, hipMemcpyDeviceToHost, c->stream));
-        c->fetchCounters();
-        c->profCollect();
-        check_counters(c);
-        fill_stats(c, st);
-    });
+    bfq_text_part part{h_fastq, len};
+    bfq_fastq_job J;
+    memset(&J, 0, sizeof J);
+    J.parts = &part; J.nparts = 1;
+    J.out_dna = h_dna; J.out_qs = h_qs; J.cap_stream = cap_stream;
+    J.out_hdr = h_hdr; J.cap_hdr = cap_hdr;
+    if (!h_dna && !h_qs && !h_hdr) return BFQ_E_ARG;
+    int rc = bfq_fastq_run_job(c, &J, st);
+    if (stream_len) *stream_len = J.stream_len;
+    if (hdr_len) *hdr_len = J.hdr_len;
+    return rc;
 }
 
 extern "C" int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp,
@@ -592,13 +655,13 @@ extern "C" int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const u
         u8 *d_hdr = nullptr;
         if (h_headers) {
             d_hdr = c->alloc<u8>(headers_len + 64);
-            if (headers_len) HIP_CHECK(hipMemcpyAsync(d_hdr, h_headers, headers_len, hipMemcpyHostToDevice, c->stream));
+            bfq_upload(c, d_hdr, h_headers, headers_len);
         }
         u8 *d_out = nullptr;
         u64 ol = bfq_fastq_format(c, r.ob, r.oq, r.roff, r.N, h_headers ? 1 : 0, d_hdr, headers_len, nullptr, &d_out);
         if (out_len) *out_len = ol;
         if (ol > cap) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
-        if (ol) HIP_CHECK(hipMemcpyAsync(h_out, d_out, ol, hipMemcpyDeviceToHost, c->stream));
+        bfq_download(c, h_out, d_out, ol);
         c->fetchCounters();
         c->profCollect();
         check_counters(c);

@@ -30,6 +30,9 @@ extern const char *const BFQ_KERNEL_NAMES[K_NUM];
 
 struct ProfRec { int id; hipEvent_t a, b; double bytes; };
 
+#define BFQ_IO_MAX_WORKERS 8
+#define BFQ_IO_STAGE_BYTES (16u << 20)
+
 // device-side counters / small outputs read back by the host (one hipMemcpy)
 struct DevCounters {
     u64 stats[8];        // bfq_stats cluster counters, same order
@@ -96,7 +99,22 @@ struct bfq_ctx {
     void sync();
     void fetchCounters();
     void zeroCounters();
+
+    // host <-> device transfers (bfq_io.hip): per-worker stream + two pinned staging buffers
+    struct IoWorker { hipStream_t stream = nullptr; char *stage[2] = {nullptr, nullptr}; hipEvent_t done[2] = {nullptr, nullptr}; };
+    IoWorker io[BFQ_IO_MAX_WORKERS];
+    int ioWorkers = 0;
+    void ioInit();
+    void ioFree();
+
+    // device copy of the FASTQ text of the current call (outside the arena: its record count sizes the arena);
+    // kept between calls, grown when a larger text arrives
+    u8 *d_text = nullptr;
+    size_t textCap = 0;
+    u8 *textBuf(size_t bytes);
 };
+void bfq_upload(bfq_ctx *c, void *d_dst, const void *h_src, size_t len);
+void bfq_download(bfq_ctx *c, void *h_dst, const void *d_src, size_t len);
 
 #define KLAUNCH(ctx, kid, bytes, kernel, grid, block, ...)                                     \
     do {                                                                                       \
@@ -157,6 +175,6 @@ void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, 
 struct DevFastq { u64 N, total; void *rec; u64 *roff; u8 *bases, *quals; u64 *lineEnd; };
 void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq);
 u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, int mode, const u8 *d_hdr,
-                     u64 hdrLen, const DevFastq *fq, u8 **d_out);
+                     u64 hdrLen, const DevFastq *fq, u8 **d_out, u64 **recOffOut = nullptr);
 void bfq_fastq_streams(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, const u8 *d_fastq,
-                       const DevFastq *fq, u8 **d_dna, u8 **d_qs, u8 **d_hdr, u64 *hdrLen);
+                       const DevFastq *fq, u8 **d_dna, u8 **d_qs, u8 **d_hdr, u64 *hdrLen, u64 **hOffOut = nullptr);

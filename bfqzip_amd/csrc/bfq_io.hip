@@ -1,0 +1,205 @@
+// bfq_io.hip -- host <-> device transfers of the FASTQ entry points and the host-side line index.
+//
+// The reference moves its data through files and pipes (`sed -n 2~4p`, `cat`, Python line
+// loops: BFQzip.py:192-251, BFQzip_parallel.py:288-360,137-179).  Here a block of FASTQ text
+// goes to the GPU as bytes and comes back as bytes, so the transfer itself is what has to be
+// fast:
+//   * a host buffer that is pinned (bfq_host_alloc / hipHostMalloc / hipHostRegister) is
+//     copied by one asynchronous DMA on the context's stream;
+//   * a pageable buffer (an mmap'ed file, a std::vector) is staged: worker threads copy
+//     chunks into their own pinned staging buffers and DMA them on their own streams, two
+//     buffers per worker, so that the CPU copy of one chunk overlaps the DMA of the other.
+// Host-side line index (bfq_text_count_lines / bfq_text_nth_newline): what the multi-GPU
+// driver needs to cut a file into the blocks of BFQzip_parallel.split_fastq without
+// parsing it (one sharded pass over the bytes).
+#include <string.h>
+#include <stdlib.h>
+#include <thread>
+#include <algorithm>
+#include "bfq_internal.h"
+
+static int io_threads()
+{
+    static const int t = [] {
+        if (const char *e = getenv("BFQ_IO_THREADS")) { int v = atoi(e); if (v >= 1 && v <= BFQ_IO_MAX_WORKERS) return v; }
+        unsigned hw = std::thread::hardware_concurrency();
+        int v = hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
+        return v;
+    }();
+    return t;
+}
+
+static bool is_pinned(const void *p)
+{
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+extern "C" void *bfq_host_alloc(uint64_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+extern "C" void bfq_host_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
+void bfq_ctx::ioInit()
+{
+    if (ioWorkers) return;
+    const int T = io_threads();
+    for (int t = 0; t < T; t++) {
+        IoWorker &w = io[t];
+        HIP_CHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) HIP_CHECK(hipHostMalloc((void **)&w.stage[k], BFQ_IO_STAGE_BYTES, hipHostMallocDefault));
+    }
+    ioWorkers = T;
+}
+void bfq_ctx::ioFree()
+{
+    for (int t = 0; t < BFQ_IO_MAX_WORKERS; t++) {
+        IoWorker &w = io[t];
+        if (w.stream) { (void)hipStreamSynchronize(w.stream); (void)hipStreamDestroy(w.stream); w.stream = nullptr; }
+        for (int k = 0; k < 2; k++) {
+            if (w.stage[k]) { (void)hipHostFree(w.stage[k]); w.stage[k] = nullptr; }
+            if (w.done[k]) { (void)hipEventDestroy(w.done[k]); w.done[k] = nullptr; }
+        }
+    }
+    ioWorkers = 0;
+}
+
+// Chunk i of the transfer belongs to worker i mod T.  `up`: host -> device, else device -> host.
+static void staged_copy(bfq_ctx *c, char *dev, char *host, size_t len, bool up)
+{
+    c->ioInit();
+    const int T = c->ioWorkers;
+    const size_t CH = BFQ_IO_STAGE_BYTES;
+    const size_t nch = (len + CH - 1) / CH;
+    hipError_t errs[BFQ_IO_MAX_WORKERS];
+    for (int t = 0; t < T; t++) errs[t] = hipSuccess;
+    auto work = [&](int t) {
+        bfq_ctx::IoWorker &w = c->io[t];
+        hipError_t e = hipSetDevice(c->device);
+        size_t pend[2] = {0, 0}, poff[2] = {0, 0};              // download: chunk waiting in each staging buffer
+        int k = 0;
+        for (size_t i = (size_t)t; i < nch && e == hipSuccess; i += (size_t)T, k ^= 1) {
+            const size_t off = i * CH, sz = std::min(CH, len - off);
+            if (up) {
+                // stage[k] was handed to the DMA two chunks ago: the stream is in order, so waiting for the
+                // previous chunk's DMA (issued from stage[k^1]) is not needed -- only stage[k]'s own
+                if (i >= (size_t)(2 * T)) e = hipEventSynchronize(w.done[k]);
+                if (e != hipSuccess) break;
+                memcpy(w.stage[k], host + off, sz);
+                e = hipMemcpyAsync(dev + off, w.stage[k], sz, hipMemcpyHostToDevice, w.stream);
+                if (e == hipSuccess) e = hipEventRecord(w.done[k], w.stream);
+            } else {
+                e = hipMemcpyAsync(w.stage[k], dev + off, sz, hipMemcpyDeviceToHost, w.stream);
+                if (e == hipSuccess) e = hipEventRecord(w.done[k], w.stream);
+                if (pend[k ^ 1]) {                               // while that DMA runs: drain the other buffer
+                    if (e == hipSuccess) e = hipEventSynchronize(w.done[k ^ 1]);
+                    if (e == hipSuccess) memcpy(host + poff[k ^ 1], w.stage[k ^ 1], pend[k ^ 1]);
+                    pend[k ^ 1] = 0;
+                }
+                pend[k] = sz; poff[k] = off;
+            }
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(w.stream);
+        if (!up && e == hipSuccess)
+            for (int q = 0; q < 2; q++)
+                if (pend[q]) memcpy(host + poff[q], w.stage[q], pend[q]);
+        errs[t] = e;
+    };
+    for (int t = 0; t < T; t++)
+        for (int k = 0; k < 2; k++)
+            if (!c->io[t].done[k]) HIP_CHECK(hipEventCreateWithFlags(&c->io[t].done[k], hipEventDisableTiming));
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+    for (int t = 0; t < T; t++)
+        if (errs[t] != hipSuccess) throw BfqError{BFQ_E_HIP, std::string("staged transfer: ") + hipGetErrorString(errs[t])};
+}
+
+// host -> device.  Ordered after everything already on the context's stream; when it returns the
+// data is either on the device (staged path) or queued on the context's stream (pinned source).
+void bfq_upload(bfq_ctx *c, void *d_dst, const void *h_src, size_t len)
+{
+    if (!len) return;
+    if (is_pinned(h_src) || len < (1u << 20)) {
+        HIP_CHECK(hipMemcpyAsync(d_dst, h_src, len, hipMemcpyHostToDevice, c->stream));
+        return;
+    }
+    c->sync();                                          // d_dst may still be in use by queued kernels
+    staged_copy(c, (char *)d_dst, (char *)h_src, len, true);
+}
+
+// device -> host, same rules; with a pageable destination the call returns with the bytes in place
+void bfq_download(bfq_ctx *c, void *h_dst, const void *d_src, size_t len)
+{
+    if (!len) return;
+    if (is_pinned(h_dst) || len < (1u << 20)) {
+        HIP_CHECK(hipMemcpyAsync(h_dst, d_src, len, hipMemcpyDeviceToHost, c->stream));
+        return;
+    }
+    c->sync();                                          // the producer kernels run on the context's stream
+    staged_copy(c, (char *)d_src, (char *)h_dst, len, false);
+}
+
+// ---------------------------------------------------------------- host-side line index
+// counts[i] = number of '\n' in bytes [i*chunk, (i+1)*chunk) of the text
+static void count_range(const uint8_t *h, uint64_t len, uint64_t chunk, uint64_t *counts, uint64_t c0, uint64_t c1)
+{
+    for (uint64_t ci = c0; ci < c1; ci++) {
+        const uint64_t b = ci * chunk, e = std::min(len, b + chunk);
+        uint64_t k = 0;
+        const uint8_t *p = h + b;
+        const uint64_t m = e - b;
+        for (uint64_t i = 0; i < m; i++) k += (p[i] == (uint8_t)'\n');   // vectorised by the compiler
+        counts[ci] = k;
+    }
+}
+extern "C" int bfq_text_count_lines(const uint8_t *h, uint64_t len, uint64_t chunk, uint64_t *counts, int threads)
+{
+    if (!chunk || (len && (!h || !counts))) return BFQ_E_ARG;
+    const uint64_t nch = (len + chunk - 1) / chunk;
+    int T = threads > 0 ? threads : 2 * io_threads();
+    if ((uint64_t)T > nch) T = (int)(nch ? nch : 1);
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(count_range, h, len, chunk, counts, nch * t / T, nch * (t + 1) / T);
+    count_range(h, len, chunk, counts, 0, nch / T);
+    for (auto &x : th) x.join();
+    return BFQ_OK;
+}
+extern "C" int64_t bfq_text_nth_newline(const uint8_t *h, uint64_t len, uint64_t k)
+{
+    for (uint64_t i = 0; i < len; i++)
+        if (h[i] == (uint8_t)'\n' && k-- == 0) return (int64_t)i;
+    return -1;
+}
+
+// number of terminator bytes of an eBWT: sizes the outputs of bfq_smooth_invert (N reads, n - N bases)
+static void count_byte_range(const uint8_t *h, uint64_t b, uint64_t e, uint8_t v, uint64_t *out)
+{
+    uint64_t k = 0;
+    for (uint64_t i = b; i < e; i++) k += (h[i] == v);
+    *out = k;
+}
+extern "C" int bfq_count_reads(const uint8_t *h_bwt, uint64_t n, int term, uint64_t *N)
+{
+    if (!N || (n && !h_bwt)) return BFQ_E_ARG;
+    int T = n > (64u << 20) ? 2 * io_threads() : 1;
+    std::vector<uint64_t> part(T, 0);
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(count_byte_range, h_bwt, n * t / T, n * (t + 1) / T, (uint8_t)term, &part[t]);
+    count_byte_range(h_bwt, 0, n / T, (uint8_t)term, &part[0]);
+    for (auto &x : th) x.join();
+    uint64_t k = 0;
+    for (int t = 0; t < T; t++) k += part[t];
+    *N = k;
+    return BFQ_OK;
+}

@@ -244,7 +244,7 @@ void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq)
 // Headers: mode 0 = "@"; 1 = d_hdr is a text of header lines (bfq_int -H); 2 = d_hdr is the FASTQ
 // text parsed into `fq` (its records' own header lines).  Returns the formatted length, text in *d_out (arena).
 u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, int mode, const u8 *d_hdr,
-                     u64 hdrLen, const DevFastq *fq, u8 **d_out)
+                     u64 hdrLen, const DevFastq *fq, u8 **d_out, u64 **recOffOut)
 {
     u64 *hStart = nullptr;
     u32 *hLen = nullptr;
@@ -274,13 +274,14 @@ u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
                 mode ? d_hdr : (const u8 *)nullptr, (const u64 *)hStart, (const u32 *)hLen, (const u64 *)recOff, N, out);
     }
     *d_out = out;
+    if (recOffOut) *recOffOut = recOff;
     return outLen;
 }
 
 // The streams of BFQzip.py --m2/--m3: *d_dna / *d_qs hold total + N bytes each; *d_hdr (when asked for) the
 // header lines of the parsed FASTQ `fq`, *hdrLen bytes.
 void bfq_fastq_streams(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, const u8 *d_fastq,
-                       const DevFastq *fq, u8 **d_dna, u8 **d_qs, u8 **d_hdr, u64 *hdrLen)
+                       const DevFastq *fq, u8 **d_dna, u8 **d_qs, u8 **d_hdr, u64 *hdrLen, u64 **hOffOut)
 {
     u8 *dna = c->alloc<u8>(total + N + 64), *qs = c->alloc<u8>(total + N + 64);
     u64 waves = N < (1u << 18) ? N : (1u << 18);
@@ -297,4 +298,35 @@ void bfq_fastq_streams(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u
     u8 *hdr = c->alloc<u8>(hl + 64);
     if (N) KLAUNCH(c, K_FASTQ, 2.0 * (double)hl, k_fq_hdr_gather, ceil_div(waves, 4), 256, d_fastq, (const FqRec *)fq->rec, (const u64 *)hOff, N, hdr);
     *d_hdr = hdr; *hdrLen = hl;
+    if (hOffOut) *hOffOut = hOff;
+}
+
+// ---- parts of a job (bfq_fastq_run_job): index of the first record of every part = number of records whose header
+// line starts before the part does; entry nparts = N
+struct PartStarts { u64 v[BFQ_MAX_PARTS + 1]; };
+__global__ void k_fq_part_index(const FqRec *__restrict__ rec, u64 N, PartStarts ps, int nparts, u64 *__restrict__ idx)
+{
+    const int p = threadIdx.x;
+    if (p > nparts) return;
+    u64 lo = 0, hi = N;                                 // first record with hdrStart >= ps.v[p]
+    while (lo < hi) {
+        u64 mid = (lo + hi) >> 1;
+        if (rec[mid].hdrStart < ps.v[p]) lo = mid + 1; else hi = mid;
+    }
+    idx[p] = (p == nparts) ? N : lo;
+}
+__global__ void k_pick_u64(const u64 *__restrict__ src, const u64 *__restrict__ idx, int count, u64 addIdx, u64 *__restrict__ out)
+{
+    const int p = threadIdx.x;
+    if (p < count) out[p] = src[idx[p]] + addIdx * idx[p];
+}
+void bfq_fastq_part_index(bfq_ctx *c, const DevFastq *fq, const u64 *h_pstart, int nparts, u64 *d_idx)
+{
+    PartStarts ps;
+    for (int p = 0; p <= BFQ_MAX_PARTS; p++) ps.v[p] = p <= nparts ? h_pstart[p] : 0;
+    KLAUNCH(c, K_FASTQ, 0.0, k_fq_part_index, 1, 64, (const FqRec *)fq->rec, fq->N, ps, nparts, d_idx);
+}
+void bfq_pick_u64(bfq_ctx *c, const u64 *d_src, const u64 *d_idx, int count, u64 addIdx, u64 *d_out)
+{
+    KLAUNCH(c, K_FASTQ, 0.0, k_pick_u64, 1, 64, d_src, d_idx, count, addIdx, d_out);
 }

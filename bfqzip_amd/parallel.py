@@ -1,28 +1,36 @@
-"""Block sharding of a read collection across GPUs: the reference's own split rule.
+"""Block sharding of a FASTQ file across GPUs: the reference's own split / merge rule, on bytes.
 
-BFQzip_parallel.py:288-323 (split_fastq): size_block = num_reads // t,
-num_blocks = num_reads // size_block; blocks 0..num_blocks-2 take size_block
-consecutive reads, the LAST block takes all remaining reads (so num_blocks may
-exceed t).  Paired mode (split_fastq_2, :325-360): block k of file 2 (same rule on
-file 2) is appended to block k of file 1; after inversion the first
-len(block k of file 1) reads go to OUT_1, the rest to OUT_2 (:153-172).
-Every block is a fully independent run of the hot path (own eBWT, clusters,
-inversion); the merge is an ordered concatenation (`cat`, :174-177).
+BFQzip_parallel.py:288-323 (split_fastq): size_block = num_reads // t, num_blocks = num_reads // size_block;
+blocks 0..num_blocks-2 take size_block consecutive reads, the LAST block takes all remaining reads (so
+num_blocks may exceed t).  Paired mode (split_fastq_2, :325-360): block k of file 2 (same rule on file 2) is
+appended to block k of file 1; after the run the first lines(block k of file 1) output lines go to OUT_1, the
+rest to OUT_2 (:153-172).  Every block is a fully independent run of the hot path (`BFQzip.py <block> --rebuild
+-0 [--headers]`, :277-285: own eBWT, clusters, inversion); the merge is an ordered concatenation (`cat`, :174-177).
 
-Multi-GPU mapping: one process per GPU (torch.distributed; backend nccl = RCCL
-on GPUs, gloo in the CPU tests), blocks dealt round-robin to ranks, no data-path
-collective; the only exchange is the ordered gather of the per-block outputs
-(variable-length byte buffers) to rank 0.
+Here: one process per GPU (torch.distributed; backend nccl = RCCL on GPUs, gloo in the CPU tests).  Nothing is
+done per read on the host:
+  * the input files are memory-mapped; every rank counts the newlines of ITS share of the bytes (host threads
+    in libbfqhip.so), the per-chunk counts are all-gathered (a few thousand integers), and block boundaries
+    are located by line number inside single 1 MiB chunks;
+  * a block = 1 byte range (2 with -p: the mate block appended) handed to Engine.fastq_job, which parses,
+    runs the whole path and formats the FASTQ text / the --m2/--m3 streams on the GPU;
+  * blocks are dealt round-robin; after every round of `world` blocks the output sizes (6 integers per block)
+    are all-gathered and each rank writes its block's bytes at their final offsets (pwrite) -- there is no
+    data-path collective and no gather of payload bytes.
 """
+import os
+import sys
 import numpy as np
+
+CHUNK = 1 << 20
 
 
 def split_blocks(num_reads, t):
-    """[(first_read, end_read)] per block, exactly as split_fastq() cuts them."""
+    """[(first_read, end_read)] per block, exactly as split_fastq() cuts them (t == 0: one block, :302-303)."""
     if num_reads <= 0:
         return []
-    t = max(1, int(t))
-    size_block = num_reads // t
+    t = int(t)
+    size_block = num_reads if t <= 0 else num_reads // t
     if size_block == 0:                       # more threads than reads: the reference divides by zero; one block
         return [(0, num_reads)]
     num_blocks = num_reads // size_block
@@ -38,155 +46,232 @@ def blocks_of_rank(num_blocks, rank, world):
     return list(range(rank, num_blocks, world))
 
 
-def slice_reads(bases, quals, roff, s, e):
-    """Reads [s,e) of a collection as its own collection."""
-    lo, hi = int(roff[s]), int(roff[e])
-    return bases[lo:hi], quals[lo:hi], (roff[s:e + 1] - roff[s]).astype(np.uint64)
+class Comm:
+    """The few integers the ranks exchange; single process when torch.distributed is not initialised."""
+
+    def __init__(self, dist=None, device=None):
+        self.dist, self.device = dist, device
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+
+    def all_gather_i64(self, vec):
+        """vec: int64 array of the same length on every rank -> array [world, len]."""
+        vec = np.ascontiguousarray(vec, np.int64)
+        if self.dist is None or self.world == 1:
+            return vec[None, :].copy()
+        import torch
+        dev = self.device if self.device is not None else torch.device("cpu")
+        mine = torch.from_numpy(vec).to(dev)
+        got = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(got, mine)
+        return np.stack([g.cpu().numpy() for g in got])
+
+    def barrier(self):
+        if self.dist is not None and self.world > 1:
+            self.dist.barrier()
 
 
-def paired_blocks(c1, c2, t):
-    """Blocks for -p: block k = reads of file-1 block k followed by reads of file-2 block k.
-    Returns [(bases, quals, roff, n_reads_from_file1)]."""
-    b1, b2 = split_blocks(len(c1[2]) - 1, t), split_blocks(len(c2[2]) - 1, t)
+def map_file(path):
+    """Read-only uint8 view of a file (nothing is read until touched)."""
+    if os.path.getsize(path) == 0:
+        return np.zeros(0, np.uint8)
+    return np.memmap(path, dtype=np.uint8, mode="r")
+
+
+class TextIndex:
+    """Line index of a memory-mapped text, built by all ranks together: rank r counts the newlines of the r-th
+    share of the chunks; cum[i] = newlines before chunk i."""
+
+    def __init__(self, buf, comm, count_fn, nth_fn, chunk=CHUNK):
+        self.buf, self.chunk, self.nth_fn = buf, chunk, nth_fn
+        n = len(buf)
+        nch = (n + chunk - 1) // chunk
+        per = (nch + comm.world - 1) // comm.world if nch else 0
+        lo, hi = min(nch, comm.rank * per), min(nch, (comm.rank + 1) * per)
+        mine = np.zeros(per, np.int64)
+        if hi > lo:
+            mine[:hi - lo] = count_fn(buf[lo * chunk:min(n, hi * chunk)], chunk).astype(np.int64)
+        allc = comm.all_gather_i64(mine).reshape(-1)[:nch] if per else np.zeros(0, np.int64)
+        self.cum = np.zeros(nch + 1, np.int64)
+        np.cumsum(allc, out=self.cum[1:])
+        self.num_lines = int(self.cum[-1]) + (1 if n and buf[n - 1] != 10 else 0)
+
+    def line_start(self, k):
+        """Byte offset at which line k (0-based) starts; k == num_lines -> end of the text."""
+        n = len(self.buf)
+        if k <= 0:
+            return 0
+        if k >= self.num_lines:
+            return n
+        j = k - 1                                                   # the newline that ends line k-1
+        ci = int(np.searchsorted(self.cum, j, side="right")) - 1
+        b = ci * self.chunk
+        off = self.nth_fn(self.buf[b:min(n, b + self.chunk)], j - int(self.cum[ci]))
+        if off < 0:
+            raise RuntimeError("line index inconsistent with the text (file changed while mapped?)")
+        return b + off + 1
+
+
+def byte_blocks(index, t):
+    """[(byte0, byte1, n_reads)] per block of split_fastq(); num_reads = num_lines // 4 (:298)."""
+    if index.num_lines % 4:
+        raise ValueError("FASTQ: number of lines is not a multiple of 4")
     out = []
-    for k in range(max(len(b1), len(b2))):
-        parts = []
-        n1 = 0
-        if k < len(b1):
-            parts.append(slice_reads(*c1, *b1[k])); n1 = b1[k][1] - b1[k][0]
-        if k < len(b2):
-            parts.append(slice_reads(*c2, *b2[k]))
-        bases = np.concatenate([p[0] for p in parts]); quals = np.concatenate([p[1] for p in parts])
-        roffs = [parts[0][2]]
-        for p in parts[1:]:
-            roffs.append(p[2][1:] + roffs[-1][-1])
-        out.append((bases, quals, np.concatenate(roffs).astype(np.uint64), n1))
+    for s, e in split_blocks(index.num_lines // 4, t):
+        out.append((index.line_start(4 * s), index.line_start(4 * e), e - s))
     return out
 
 
-def run_blocks(run_block, bases, quals, roff, t, dist=None, device=None):
-    """Process a collection block-wise.  run_block(bases, quals, roff) -> (out_bases, out_quals).
-    With torch.distributed initialised (dist), blocks are dealt round-robin to the ranks and
-    rank 0 returns the ordered concatenation (other ranks return None)."""
-    blocks = split_blocks(len(roff) - 1, t)
-    rank = dist.get_rank() if dist is not None else 0
-    world = dist.get_world_size() if dist is not None else 1
-    mine = {}
-    for k in blocks_of_rank(len(blocks), rank, world):
-        bb, bq, br = slice_reads(bases, quals, roff, *blocks[k])
-        ob, oq = run_block(bb, bq, br)
-        mine[k] = (np.ascontiguousarray(ob, np.uint8), np.ascontiguousarray(oq, np.uint8))
-    if dist is None or world == 1:
-        ks = sorted(mine)
-        return (np.concatenate([mine[k][0] for k in ks]) if ks else np.zeros(0, np.uint8),
-                np.concatenate([mine[k][1] for k in ks]) if ks else np.zeros(0, np.uint8))
-    return gather_blocks(mine, blocks, roff, dist, device)
+def output_names(inputs, out, paired):
+    """Merged FASTQ names as BFQzip_parallel.py:142-153 builds them (+ the stream names of BFQzip.py:192-251)."""
+    root1, ext1 = os.path.splitext(inputs[0])
+    if not out:
+        fq = [root1 + ".cat" + ext1]
+        base = [root1 + ".cat"]
+        if paired:
+            root2, ext2 = os.path.splitext(inputs[1])
+            fq.append(root2 + ".cat" + ext2); base.append(root2 + ".cat")
+    elif paired:
+        fq = [out + "_1" + ext1, out + "_2" + ext1]
+        base = [out + "_1", out + "_2"]
+    else:
+        fq = [out + ext1]
+        base = [out]
+    return [{"fastq": f, "dna": f + ".dna", "qs": f + ".qs", "hdr": b + ".h"} for f, b in zip(fq, base)]
 
 
-def gather_blocks(mine, blocks, roff, dist, device=None):
-    """Ordered gather of per-block byte buffers to rank 0: sizes are known from the split
-    (inversion keeps read lengths), payloads travel as one padded uint8 tensor per rank."""
-    import torch
-    rank, world = dist.get_rank(), dist.get_world_size()
-    dev = device if device is not None else torch.device("cpu")
-    sizes = [int(roff[e]) - int(roff[s]) for s, e in blocks]
-    per_rank = [sum(sizes[k] for k in blocks_of_rank(len(blocks), r, world)) for r in range(world)]
-    cap = max(per_rank) if per_rank else 0
-    buf = torch.zeros(2 * cap if cap else 1, dtype=torch.uint8, device=dev)
-    o = 0
-    for k in sorted(mine):
-        n = sizes[k]
-        buf[o:o + n] = torch.from_numpy(mine[k][0]).to(dev)
-        buf[cap + o:cap + o + n] = torch.from_numpy(mine[k][1]).to(dev)
-        o += n
-    got = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
-    dist.gather(buf, got, dst=0)
-    if rank != 0:
-        return None
-    total = int(roff[-1])
-    ob = np.empty(total, np.uint8); oq = np.empty(total, np.uint8)
-    for r in range(world):
-        g = got[r].cpu().numpy()
-        o = 0
-        for k in blocks_of_rank(len(blocks), r, world):
-            n = sizes[k]
-            lo = int(roff[blocks[k][0]])
-            ob[lo:lo + n] = g[o:o + n]
-            oq[lo:lo + n] = g[cap + o:cap + o + n]
-            o += n
-    return ob, oq
+KINDS = ("fastq", "dna", "qs", "hdr")
+
+
+def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fastq=True, want_streams=False,
+              want_hdr=False, out_bufs=None, log=None):
+    """The whole multi-GPU job.  eng: Engine-like (fastq_job, text_line_counts/text_nth_newline via `eng.host`).
+    Returns per-rank totals {"blocks", "reads", "bases", "stats"} (stats summed over this rank's blocks)."""
+    host = eng.host
+    bufs = [map_file(p) for p in inputs]
+    idx = [TextIndex(b, comm, host.text_line_counts, host.text_nth_newline) for b in bufs]
+    blocks = [byte_blocks(i, t) for i in idx]
+    nblocks = len(blocks[0])                                         # the blocks of file 1 drive the run (:97-119)
+    kinds = [k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w]
+    nout = 2 if paired else 1
+    if comm.rank == 0:                                               # create / truncate the outputs once
+        for o in range(nout):
+            for k in kinds:
+                open(names[o][k], "wb").close()
+    comm.barrier()
+    fds = {(o, k): os.open(names[o][k], os.O_WRONLY) for o in range(nout) for k in kinds}
+    cursor = np.zeros((nout, 4), np.int64)                           # next free byte of every output file
+    tot = {"blocks": 0, "reads": 0, "bases": 0, "stats": {}}
+    out_bufs = out_bufs if out_bufs is not None else {}
+    rounds = (nblocks + comm.world - 1) // comm.world
+    for rd in range(rounds):
+        k = rd * comm.world + comm.rank
+        sizes = np.zeros((2, 4), np.int64)
+        res = None
+        if k < nblocks:
+            b0, b1, _ = blocks[0][k]
+            parts = [bufs[0][b0:b1]]
+            if paired and k < len(blocks[1]):
+                c0, c1, _ = blocks[1][k]
+                parts.append(bufs[1][c0:c1])
+            res = eng.fastq_job(parts, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr,
+                                out=out_bufs)
+            cut = {"fastq": res.part_fastq_off, "dna": res.part_stream_off, "qs": res.part_stream_off,
+                   "hdr": res.part_hdr_off}
+            for o in range(nout):
+                for ki, kind in enumerate(KINDS):
+                    if kind in kinds:
+                        lo = cut[kind][o] if o < len(parts) else cut[kind][-1]
+                        hi = cut[kind][o + 1] if o < len(parts) else cut[kind][-1]
+                        sizes[o, ki] = hi - lo
+            tot["blocks"] += 1; tot["reads"] += res.n_reads; tot["bases"] += res.total_bases
+            for key, v in res.stats.items():
+                if key.startswith("n_"):
+                    continue
+                tot["stats"][key] = tot["stats"].get(key, 0) + v
+            if log:
+                log(f"block {k + 1}/{nblocks}: {res.n_reads} reads, {res.total_bases} bases")
+        allsz = comm.all_gather_i64(sizes.reshape(-1)).reshape(comm.world, 2, 4)
+        before = allsz[:comm.rank].sum(axis=0)                       # blocks of this round that come first
+        if res is not None:
+            data = {"fastq": res.fastq, "dna": res.dna, "qs": res.qs, "hdr": res.hdr}
+            for o in range(nout):
+                for ki, kind in enumerate(KINDS):
+                    if kind in kinds and sizes[o, ki]:
+                        lo = cut[kind][o]
+                        os.pwrite(fds[(o, kind)], memoryview(data[kind][lo:lo + int(sizes[o, ki])]),
+                                  int(cursor[o, ki] + before[o, ki]))
+        cursor += allsz.sum(axis=0)[:nout]
+    for fd in fds.values():
+        os.close(fd)
+    comm.barrier()
+    return tot
 
 
 def main(argv=None):
-    """`torchrun --nproc-per-node G -m bfqzip_amd.parallel in.fastq [in2.fastq -p] -o OUT -t n [--headers] [...]`
+    """`python -m torch.distributed.run --nproc-per-node G -m bfqzip_amd.parallel in.fastq [in2.fastq -p] -o OUT -t n [-H]`
 
-    The multi-GPU counterpart of `BFQzip_parallel.py in.fastq -o OUT -t n -0`: same block split, one block per
-    GPU at a time, outputs merged in block order into OUT.fq (or OUT_1.fq / OUT_2.fq with -p).  Without torchrun it
-    runs all blocks on GPU 0."""
-    import argparse, os
+    The multi-GPU counterpart of `BFQzip_parallel.py in.fastq [in2.fastq -p] -o OUT -t n -0` (same flags, same
+    block split, same output names: OUT<ext> or OUT_1<ext> / OUT_2<ext>), one block per GPU at a time.  --m2 / --m3
+    additionally write the streams BFQzip.py cuts with sed (<fastq>.dna, <fastq>.qs; --m3: OUT.h and header lines
+    kept).  Without torchrun it runs all blocks on GPU 0."""
+    import argparse
     import torch
-    from . import api, fastq
+    from . import api
     ap = argparse.ArgumentParser(prog="bfqzip_amd.parallel")
-    ap.add_argument("input"); ap.add_argument("input2", nargs="?")
-    ap.add_argument("-o", "--out", required=True)
-    ap.add_argument("-t", "--threads", type=int, default=1, help="number of blocks (BFQzip_parallel.py -t)")
+    ap.add_argument("input", nargs="+")
+    ap.add_argument("-o", "--out", default="")
+    ap.add_argument("-T", "--mcl", default="", help="minimum context length (bfq_int -k)")
+    ap.add_argument("-Q", "--rv", default="", help="constant replacement value (bfq_int -v)")
+    ap.add_argument("-H", "--headers", action="store_true", help="store original headers")
+    ap.add_argument("-0", "--m0", action="store_true", help="do not compress (always the case: step 5 is out of scope)")
     ap.add_argument("-p", "--paired", action="store_true")
-    ap.add_argument("--headers", action="store_true")
-    ap.add_argument("--m2", action="store_true", help="also write OUT.fq.dna and OUT.fq.qs (BFQzip.py:231-249)")
-    ap.add_argument("--m3", action="store_true", help="--m2 plus OUT.h (BFQzip.py:195-201)")
-    ap.add_argument("-T", dest="k", type=int, default=16); ap.add_argument("-Q", dest="v", default=">")
+    ap.add_argument("-t", "--threads", type=int, default=0, help="number of blocks")
+    ap.add_argument("-c", "--check", action="store_true", help="accepted: records are always checked on the GPU")
+    ap.add_argument("-v", type=int, default=0)
+    ap.add_argument("--m2", action="store_true", help="also write <fastq>.dna and <fastq>.qs (BFQzip.py:231-249)")
+    ap.add_argument("--m3", action="store_true", help="--m2 plus OUT.h, headers kept (BFQzip.py:60-64,192-201)")
+    ap.add_argument("--streams-only", action="store_true", help="with --m2/--m3: do not write the merged FASTQ text")
+    ap.add_argument("--pinned", action="store_true", help="page-locked output buffers (direct DMA)")
     ap.add_argument("--M", type=int, default=2); ap.add_argument("--B", type=int, default=0)
     a = ap.parse_args(argv)
+    if a.paired and len(a.input) != 2:
+        print("=== ERROR ===\npaired end mode", file=sys.stderr)
+        return 1
+    if a.m3:
+        a.headers = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     if world > 1:
         import torch.distributed as dist
-        backend = os.environ.get("BFQ_BACKEND", "nccl")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend)
-    rank = dist.get_rank() if dist else 0
+        dist.init_process_group(os.environ.get("BFQ_BACKEND", "nccl"))
     local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
     dev = torch.device("cuda", local) if (dist and dist.get_backend() == "nccl") else None
-    eng = api.Engine(local, k=a.k, m=5, v=ord(a.v), M=a.M, B=a.B)          # -m 5: what BFQzip.py passes (BFQzip.py:215)
-
-    def run(b, q, r):
-        ob, oq, st = eng.run_reads(b, q, r)
-        return ob, oq
-
-    c1 = fastq.read_fastq(a.input)
-    if a.paired and a.input2:
-        c2 = fastq.read_fastq(a.input2)
-        blocks = paired_blocks(c1[:3], c2[:3], a.threads)
-        o1, o2 = [], []
-        for k, (bb, bq, br, n1) in enumerate(blocks):                       # paired: blocks stay on this rank's GPU
-            if k % world != rank:
-                continue
-            ob, oq = run(bb, bq, br)
-            cut = int(br[n1])
-            o1.append((k, fastq.format_fastq(ob[:cut], oq[:cut], br[:n1 + 1])))
-            o2.append((k, fastq.format_fastq(ob[cut:], oq[cut:], (br[n1:] - br[n1]).astype(np.uint64))))
-        if dist:
-            g1 = [None] * world; g2 = [None] * world
-            dist.all_gather_object(g1, o1); dist.all_gather_object(g2, o2)
-            o1 = [x for g in g1 for x in g]; o2 = [x for g in g2 for x in g]
-        if rank == 0:
-            open(a.out + "_1.fq", "wb").write(b"".join(t for _, t in sorted(o1)))
-            open(a.out + "_2.fq", "wb").write(b"".join(t for _, t in sorted(o2)))
-    else:
-        b, q, r, h = c1
-        res = run_blocks(run, b, q, r, a.threads, dist=dist, device=dev)
-        if rank == 0:
-            open(a.out + ".fq", "wb").write(fastq.format_fastq(res[0], res[1], r, h if a.headers else None))
-            if a.m2 or a.m3:
-                open(a.out + ".fq.dna", "wb").write(fastq.format_lines(res[0], r))
-                open(a.out + ".fq.qs", "wb").write(fastq.format_lines(res[1], r))
-            if a.m3:
-                open(a.out + ".h", "wb").write(b"".join(x + b"\n" for x in h))
+    comm = Comm(dist, dev)
+    par = dict(m=5, M=a.M, B=a.B)                                    # -m 5: what BFQzip.py passes (BFQzip.py:215)
+    if a.mcl:
+        par["k"] = int(a.mcl)
+    if a.rv:
+        par["v"] = ord(a.rv)
+    eng = api.Engine(local, **par)
+    names = output_names(a.input, a.out, a.paired)
+    streams = a.m2 or a.m3
+    bufs = {}
+    if a.pinned:
+        cap = max(os.path.getsize(p) for p in a.input) * (2 if a.paired else 1) // max(1, a.threads) * 2 + (1 << 20)
+        pins = {k: api.PinnedBuffer(cap) for k in (["fastq"] if not a.streams_only else []) + (["dna", "qs"] if streams else []) + (["hdr"] if a.m3 else [])}
+        bufs = {k: p.array for k, p in pins.items()}
+    log = (lambda m: print(f"[rank {comm.rank}] {m}", flush=True)) if a.v else None
+    tot = run_files(eng, comm, a.input, a.threads, names, paired=a.paired, headers=a.headers,
+                    want_fastq=not (streams and a.streams_only), want_streams=streams, want_hdr=a.m3, out_bufs=bufs, log=log)
+    if a.v:
+        print(f"[rank {comm.rank}] {tot}", flush=True)
     eng.close()
     if dist:
-        dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

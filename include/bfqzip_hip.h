@@ -128,6 +128,40 @@ int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_b
                             const uint8_t *h_headers, uint64_t headers_len,
                             uint8_t *h_out, uint64_t cap, uint64_t *out_len, bfq_stats *st);
 
+/* ---- one block of BFQzip_parallel.py as one call (BFQzip_parallel.py:277-285 runs `BFQzip.py <block> --rebuild -0
+ * [--headers]` per block; :325-360 appends mate block k of file 2 to block k of file 1; :153-172 cuts the
+ * block's output back into OUT_1 / OUT_2 by line count).
+ * The block's text is given as 1..BFQ_MAX_PARTS byte ranges (mmap'ed file ranges or pinned buffers; a part that
+ * lacks its final newline gets one) processed as ONE collection, parts in order.  Any of the outputs may be
+ * asked for in the same pass: the FASTQ text (out_fastq), the --m2/--m3 streams (out_dna, out_qs, out_hdr).
+ * part_*[p] = where part p's share of each output starts (entry nparts = the end), part_reads[p] = index of its
+ * first read.  Pinned host buffers (bfq_host_alloc) are transferred by direct DMA, pageable ones through the
+ * library's pinned staging pipeline. */
+#define BFQ_MAX_PARTS 4
+typedef struct bfq_text_part { const uint8_t *data; uint64_t len; } bfq_text_part;
+typedef struct bfq_fastq_job {
+    const bfq_text_part *parts; int32_t nparts;
+    int32_t keep_headers;                     /* FASTQ text: header lines verbatim (BFQzip.py --headers) or "@"  */
+    uint8_t *out_fastq; uint64_t cap_fastq;   /* NULL: not wanted; bfq_fastq_out_bound() / input length + 16     */
+    uint8_t *out_dna, *out_qs; uint64_t cap_stream;   /* total bases + reads bytes each                           */
+    uint8_t *out_hdr; uint64_t cap_hdr;       /* `sed -n 1~4p` of the input                                      */
+    /* results */
+    uint64_t fastq_len, stream_len, hdr_len, n_reads, total_bases;
+    uint64_t part_reads[BFQ_MAX_PARTS + 1], part_fastq_off[BFQ_MAX_PARTS + 1],
+             part_stream_off[BFQ_MAX_PARTS + 1], part_hdr_off[BFQ_MAX_PARTS + 1];
+} bfq_fastq_job;
+int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *job, bfq_stats *st);
+
+/* Pinned (page-locked) host memory for the buffers above. */
+void *bfq_host_alloc(uint64_t bytes);
+void  bfq_host_free(void *p);
+
+/* Host-side line index of a text (what BFQzip_parallel.py:295-319 does with Python line loops): counts[i] =
+ * number of '\n' in bytes [i*chunk, (i+1)*chunk), computed by `threads` threads (0: default);
+ * bfq_text_nth_newline = offset of the k-th (0-based) '\n' of the range or -1.  Pure host functions (no GPU). */
+int     bfq_text_count_lines(const uint8_t *h_text, uint64_t len, uint64_t chunk, uint64_t *counts, int threads);
+int64_t bfq_text_nth_newline(const uint8_t *h_text, uint64_t len, uint64_t k);
+
 /* Device-resident eBWT of the last bfq_run_reads*() / bfq_build_ebwt() call
  * (valid until the next call on the context): copies to host. Any may be NULL.
  * h_bwtqs receives the permuted qualities as built (before smoothing). */

@@ -1,74 +1,99 @@
-"""GPU test of the sharded path: BFQzip_parallel's split, one process per rank (gloo here, both
-ranks on the single GPU of the test box), the real engine per block, ordered gather on rank 0.
-Expected md5s: the reference's own BFQzip_parallel.py runs."""
-import hashlib, os, sys
+"""GPU tests of the sharded path (bfqzip_amd/parallel.py): BFQzip_parallel's split on byte ranges, one process per
+rank (gloo here, both ranks on the single GPU of the test box), the real engine per block (bfq_fastq_run_job),
+outputs written at their final offsets.
+Expected md5s: the reference's own BFQzip_parallel.py runs; the large paired case (BASELINE
+config 4's shape: -p, M=1, --m3 streams, headers) is checked block by block against the oracle."""
+import hashlib, os, subprocess, sys
+import numpy as np
 import pytest
 from tests import util
+from tests.test_parallel_gloo import MD5, MD5_P1, MD5_P2, EXAMPLE, md5file, paired_inputs, check_streams
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, t, q):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    sys.path.insert(0, ROOT)
-    import torch.distributed as dist
-    from bfqzip_amd import api, fastq, parallel
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    eng = api.Engine(0, m=5)
-    def run(b, qq, r):
-        ob, oq, st = eng.run_reads(b, qq, r)
-        return ob, oq
-    b, qq, r, h, *_ = util.golden_set("example")
-    res = parallel.run_blocks(run, b, qq, r, t, dist=dist)
-    if rank == 0:
-        q.put(hashlib.md5(fastq.format_fastq(res[0], res[1], r)).hexdigest())
-    dist.barrier()
-    eng.close()
-    dist.destroy_process_group()
+def _launch(world, args, tmp, timeout=900):
+    """`python -m torch.distributed.run --nproc-per-node world -m bfqzip_amd.parallel ...` over gloo (one GPU)."""
+    env = dict(os.environ, BFQ_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    port = 29700 + (os.getpid() * 11 + len(" ".join(args))) % 2000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "bfqzip_amd.parallel"] + args
+    if world == 1:
+        cmd = [sys.executable, "-m", "bfqzip_amd.parallel"] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+    return r.stdout.decode()
 
 
-@pytest.mark.parametrize("t,md5", [(2, "d2aac3c45dda67ec3f769273ea6a5568"), (8, "4ada980195fd8d6fb206408c4f892bc6")])
-def test_two_ranks_real_engine(t, md5):
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29700 + (os.getpid() % 2000) + t
-    ps = [ctx.Process(target=_worker, args=(rk, 2, port, t, q)) for rk in range(2)]
-    for p in ps:
-        p.start()
-    got = q.get(timeout=300)
-    for p in ps:
-        p.join(timeout=120)
-        assert p.exitcode == 0
-    assert got == md5
-
-
-def test_parallel_cli_single_process(tmp_path):
-    """`python -m bfqzip_amd.parallel` without torchrun = all blocks on GPU 0; same files as BFQzip_parallel.py -t n -0."""
-    import subprocess
-    fq = os.path.join(util.GOLDEN, "example.fastq")
+@pytest.mark.parametrize("world,t", [(1, 8), (2, 2), (2, 8)])
+def test_sharded_runs_match_reference_driver(world, t, tmp_path):
     out = str(tmp_path / "OUT")
-    r = subprocess.run([sys.executable, "-m", "bfqzip_amd.parallel", fq, "-o", out, "-t", "8"], cwd=ROOT,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    assert r.returncode == 0, r.stdout.decode()[-2000:]
-    assert hashlib.md5(open(out + ".fq", "rb").read()).hexdigest() == "4ada980195fd8d6fb206408c4f892bc6"
-    # --m3: the streams BFQzip.py cuts with sed -n 2~4p / 4~4p / 1~4p (BFQzip.py:19-21)
-    r = subprocess.run([sys.executable, "-m", "bfqzip_amd.parallel", fq, "-o", out, "-t", "8", "--m3"], cwd=ROOT,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    assert r.returncode == 0, r.stdout.decode()[-2000:]
-    lines = open(out + ".fq", "rb").read().split(b"\n")[:-1]
-    assert open(out + ".fq.dna", "rb").read() == b"".join(x + b"\n" for x in lines[1::4])
-    assert open(out + ".fq.qs", "rb").read() == b"".join(x + b"\n" for x in lines[3::4])
-    assert open(out + ".h", "rb").read() == b"".join(x + b"\n" for x in open(fq, "rb").read().split(b"\n")[:-1][0::4])
-    # paired: reads_1 / reads_2 of the reference's example = the two halves of the "paired" golden input
-    from bfqzip_amd import fastq, parallel
-    b, q, rr, h, *_ = util.golden_set("paired")
-    c1 = parallel.slice_reads(b, q, rr, 0, 100); c2 = parallel.slice_reads(b, q, rr, 100, 200)
-    f1, f2 = str(tmp_path / "r1.fastq"), str(tmp_path / "r2.fastq")
-    open(f1, "wb").write(fastq.format_fastq(*c1, h[:100])); open(f2, "wb").write(fastq.format_fastq(*c2, h[100:]))
-    r = subprocess.run([sys.executable, "-m", "bfqzip_amd.parallel", f1, f2, "-p", "-o", out, "-t", "2"], cwd=ROOT,
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
-    assert r.returncode == 0, r.stdout.decode()[-2000:]
-    assert hashlib.md5(open(out + "_1.fq", "rb").read()).hexdigest() == "0869c40b37c0d1149f7644025b7bffda"
-    assert hashlib.md5(open(out + "_2.fq", "rb").read()).hexdigest() == "26b0df769ae25a5663f953c55d00ab83"
+    _launch(world, [EXAMPLE, "-o", out, "-t", str(t), "-0"], str(tmp_path))
+    assert md5file(out + ".fastq") == MD5[t]
+
+
+def test_streams_headers_and_paired(tmp_path):
+    out = str(tmp_path / "OUT")
+    # --m3: the streams BFQzip.py cuts with sed -n 2~4p / 4~4p / 1~4p (BFQzip.py:19-21), header lines kept
+    _launch(2, [EXAMPLE, "-o", out, "-t", "8", "--m3"], str(tmp_path))
+    from bfqzip_amd import parallel
+    check_streams(parallel.output_names([EXAMPLE], out, False), [EXAMPLE])
+    # paired
+    f1, f2 = paired_inputs(str(tmp_path))
+    _launch(2, [f1, f2, "-p", "-o", out, "-t", "2"], str(tmp_path))
+    assert md5file(out + "_1.fastq") == MD5_P1 and md5file(out + "_2.fastq") == MD5_P2
+    _launch(1, [f1, f2, "-p", "-o", out, "-t", "2", "--m3", "--pinned"], str(tmp_path))
+    check_streams(parallel.output_names([f1, f2], out, True), [f1, f2])
+    for k, md in ((1, MD5_P1), (2, MD5_P2)):
+        fq = open(out + f"_{k}.fastq", "rb").read().split(b"\n")[:-1]
+        assert hashlib.md5(b"".join((b"@" if i % 4 == 0 else x) + b"\n" for i, x in enumerate(fq))).hexdigest() == md
+
+
+def _synth_fastq(path, spec_seed, n_reads, L, tag):
+    """Seeded synthetic reads as a FASTQ file with distinct header lines of varying length."""
+    from bfqzip_amd import api, fastq
+    b, q, r = api.synth_host(api.synth_spec(n_reads, L, seed=spec_seed))
+    idx = np.arange(n_reads)
+    hdr = np.char.add(np.char.add("@SYN.", idx.astype(str)), np.where(idx % 3 == 0, f" {tag} len={L}", f"/{tag}"))
+    h = fastq.HeaderSpans.from_list([x.encode() for x in hdr.tolist()])
+    open(path, "wb").write(fastq.format_fastq(b, q, r, h))
+
+
+def test_paired_m1_streams_3M_reads_two_ranks(orc, tmp_path):
+    """BASELINE config 4's shape at test size: paired-end, M=1 (mean-error smoothing), --m3 (DNA / QS / header streams,
+    header lines kept), 2 x 1.6 M reads of 40 bp, -t 8 (8 blocks of 200 k + 200 k reads), 2 ranks.
+    Blocks 0, 3 and 7 are recomputed by the oracle and compared byte for byte with their share of every output file;
+    all blocks: sizes, header lines and stream/FASTQ consistency."""
+    from bfqzip_amd import parallel, api, fastq
+    N, L, T = 1_600_000, 40, 8
+    f1, f2 = str(tmp_path / "s_1.fastq"), str(tmp_path / "s_2.fastq")
+    _synth_fastq(f1, 777, N, L, "1"); _synth_fastq(f2, 778, N, L, "2")
+    out = str(tmp_path / "OUT")
+    _launch(2, [f1, f2, "-p", "-o", out, "-t", str(T), "--m3", "--M", "1"], str(tmp_path), timeout=1500)
+    names = parallel.output_names([f1, f2], out, True)
+    check_streams(names, [f1, f2])                                                  # all blocks: streams == sed of the FASTQ
+    ins = [np.fromfile(f, np.uint8) for f in (f1, f2)]
+    comm = parallel.Comm()
+    blocks = [parallel.byte_blocks(parallel.TextIndex(a, comm, api.text_line_counts, api.text_nth_newline), T) for a in ins]
+    assert len(blocks[0]) == T and all(n == N // T for _, _, n in blocks[0])
+    outs = [{k: np.fromfile(nm[k], np.uint8) for k in ("fastq", "dna", "qs", "hdr")} for nm in names]
+    for o in range(2):
+        assert len(outs[o]["fastq"]) == len(ins[o]) and len(outs[o]["dna"]) == N * (L + 1)   # records keep their size
+    eng = util.OracleEngine(orc, m=5, M=1)
+    for k in (0, 3, T - 1):
+        parts = [ins[o][blocks[o][k][0]:blocks[o][k][1]] for o in range(2)]
+        ref = eng.fastq_job(parts, keep_headers=True, fastq=True, streams=True, hdr=True)
+        assert ref.stats["qs_smoothed"] > 0
+        for o in range(2):
+            b0, b1, _ = blocks[o][k]
+            s0 = k * (N // T) * (L + 1)
+            h0 = int(np.count_nonzero(ins[o][:b0] == 10)) // 4                    # reads before the block
+            hoff = len(b"".join(x + b"\n" for x in bytes(ins[o][:b0]).split(b"\n")[0::4][:h0]))
+            lo, hi = ref.part_fastq_off[o], ref.part_fastq_off[o + 1]
+            assert np.array_equal(outs[o]["fastq"][b0:b1], ref.fastq[lo:hi]), (k, o, "fastq")
+            lo, hi = ref.part_stream_off[o], ref.part_stream_off[o + 1]
+            assert np.array_equal(outs[o]["dna"][s0:s0 + hi - lo], ref.dna[lo:hi]), (k, o, "dna")
+            assert np.array_equal(outs[o]["qs"][s0:s0 + hi - lo], ref.qs[lo:hi]), (k, o, "qs")
+            lo, hi = ref.part_hdr_off[o], ref.part_hdr_off[o + 1]
+            assert np.array_equal(outs[o]["hdr"][hoff:hoff + hi - lo], ref.hdr[lo:hi]), (k, o, "hdr")

@@ -1,7 +1,8 @@
-"""CPU tests of the multi-GPU sharding path: BFQzip_parallel's split rule, the paired
-merge rule and the ordered gather, run as 2 processes over gloo.  The per-block
-engine is the CPU oracle here (no GPU in this tier); on GPUs the same code path is
-driven with bfqzip_amd.api.Engine.run_reads (tests/test_gpu_parity.py)."""
+"""CPU tests of the multi-GPU sharding path (bfqzip_amd/parallel.py): BFQzip_parallel's split rule on byte ranges of
+memory-mapped files, the paired rule, the per-round size exchange and the offset writes, single process and as 2
+processes over gloo.  The per-block engine is the CPU oracle here (tests/util.OracleEngine; no GPU in this tier);
+tests/test_gpu_parallel.py drives the same code with bfqzip_amd.api.Engine.
+Expected md5s: the reference's own BFQzip_parallel.py runs on its example files."""
 import hashlib, os, sys
 import numpy as np
 import pytest
@@ -9,6 +10,23 @@ from bfqzip_amd import fastq, parallel
 from tests import util
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXAMPLE = os.path.join(util.GOLDEN, "example.fastq")
+MD5 = {2: "d2aac3c45dda67ec3f769273ea6a5568", 8: "4ada980195fd8d6fb206408c4f892bc6"}
+MD5_P1, MD5_P2 = "0869c40b37c0d1149f7644025b7bffda", "26b0df769ae25a5663f953c55d00ab83"
+
+
+def md5file(p):
+    return hashlib.md5(open(p, "rb").read()).hexdigest()
+
+
+def paired_inputs(tmp):
+    """reads_1 / reads_2 of the reference's example = the two halves of the "paired" golden input."""
+    b, q, r, h, *_ = util.golden_set("paired")
+    f1, f2 = os.path.join(tmp, "r1.fastq"), os.path.join(tmp, "r2.fastq")
+    cut = int(r[100])
+    open(f1, "wb").write(fastq.format_fastq(b[:cut], q[:cut], r[:101], h[:100]))
+    open(f2, "wb").write(fastq.format_fastq(b[cut:], q[cut:], r[100:] - r[100], h[100:]))
+    return f1, f2
 
 
 def test_split_rule_matches_reference_driver():
@@ -18,69 +36,138 @@ def test_split_rule_matches_reference_driver():
     # num_blocks may exceed t: 10 reads, t=4 -> size_block 2 -> 5 blocks
     assert parallel.split_blocks(10, 4) == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 10)]
     assert parallel.split_blocks(7, 1) == [(0, 7)]
+    assert parallel.split_blocks(7, 0) == [(0, 7)]                 # -t 0: one block (BFQzip_parallel.py:302-303)
     assert parallel.split_blocks(0, 3) == []
 
 
-def _oracle_block(orc):
-    p = orc.params(m=5)
-    def run(b, q, r):
-        ob, oq, st = orc.run_reads(b, q, r, p)
-        return ob, oq
-    return run
+def test_line_index_and_byte_blocks():
+    from bfqzip_amd import api
+    buf = np.frombuffer(open(EXAMPLE, "rb").read(), np.uint8)
+    text = buf.tobytes()
+    lines = text.split(b"\n")[:-1]
+    for chunk in (97, 4096, 1 << 20):
+        idx = parallel.TextIndex(buf, parallel.Comm(), api.text_line_counts, api.text_nth_newline, chunk=chunk)
+        assert idx.num_lines == 400
+        for k in (0, 1, 4, 48, 399, 400):
+            assert idx.line_start(k) == sum(len(x) + 1 for x in lines[:k])
+        bl = parallel.byte_blocks(idx, 8)
+        assert [n for _, _, n in bl] == [12] * 7 + [16] and bl[0][0] == 0 and bl[-1][1] == len(text)
+        assert all(bl[i][1] == bl[i + 1][0] for i in range(7))
+    # a last line without newline still counts
+    idx = parallel.TextIndex(buf[:-1], parallel.Comm(), api.text_line_counts, api.text_nth_newline, chunk=1000)
+    assert idx.num_lines == 400 and idx.line_start(400) == len(text) - 1
+    assert api.text_nth_newline(b"ab\ncd\n", 1) == 5 and api.text_nth_newline(b"ab", 0) == -1
 
 
-@pytest.mark.parametrize("t,md5", [(2, "d2aac3c45dda67ec3f769273ea6a5568"), (8, "4ada980195fd8d6fb206408c4f892bc6")])
-def test_sharded_output_equals_reference_parallel_run(orc, t, md5):
-    """md5s: BFQzip_parallel.py example/reads.fastq -t {2,8} -0 driving the compiled reference."""
-    b, q, r, h, *_ = util.golden_set("example")
-    ob, oq = parallel.run_blocks(_oracle_block(orc), b, q, r, t)
-    assert hashlib.md5(fastq.format_fastq(ob, oq, r)).hexdigest() == md5
+def test_output_names_follow_the_reference():
+    n = parallel.output_names(["d/in.fastq"], "OUT", False)
+    assert n[0]["fastq"] == "OUT.fastq" and n[0]["dna"] == "OUT.fastq.dna" and n[0]["hdr"] == "OUT.h"
+    n = parallel.output_names(["a.fq", "b.fq"], "OUT", True)
+    assert [x["fastq"] for x in n] == ["OUT_1.fq", "OUT_2.fq"]
+    n = parallel.output_names(["a.fastq", "b.fastq"], "", True)
+    assert [x["fastq"] for x in n] == ["a.cat.fastq", "b.cat.fastq"]          # BFQzip_parallel.py:142-147
 
 
-def test_paired_blocks_rule(orc):
-    """-p -t 2: mate block k appended to block k; outputs split back by the block-1 read count (SURVEY App. B md5s)."""
-    b, q, r, h, *_ = util.golden_set("paired")     # reads_1 followed by reads_2 (100 + 100 reads)
-    c1 = parallel.slice_reads(b, q, r, 0, 100); c2 = parallel.slice_reads(b, q, r, 100, 200)
-    run = _oracle_block(orc)
-    o1b, o1q, o1r, o2b, o2q, o2r = [], [], [0], [], [], [0]
-    for bb, bq, br, n1 in parallel.paired_blocks(c1, c2, 2):
-        ob, oq = run(bb, bq, br)
-        cut = int(br[n1])
-        o1b.append(ob[:cut]); o1q.append(oq[:cut]); o2b.append(ob[cut:]); o2q.append(oq[cut:])
-        o1r += list(o1r[-1] + (br[1:n1 + 1])); o2r += list(o2r[-1] + (br[n1 + 1:] - br[n1]))
-    f1 = fastq.format_fastq(np.concatenate(o1b), np.concatenate(o1q), np.array(o1r, np.uint64))
-    f2 = fastq.format_fastq(np.concatenate(o2b), np.concatenate(o2q), np.array(o2r, np.uint64))
-    assert hashlib.md5(f1).hexdigest() == "0869c40b37c0d1149f7644025b7bffda"
-    assert hashlib.md5(f2).hexdigest() == "26b0df769ae25a5663f953c55d00ab83"
+@pytest.mark.parametrize("t", [2, 8])
+def test_sharded_output_equals_reference_parallel_run(orc, t, tmp_path):
+    eng = util.OracleEngine(orc, m=5)
+    names = parallel.output_names([EXAMPLE], str(tmp_path / "OUT"), False)
+    tot = parallel.run_files(eng, parallel.Comm(), [EXAMPLE], t, names)
+    assert md5file(names[0]["fastq"]) == MD5[t]
+    assert tot["reads"] == 100 and tot["blocks"] == t
 
 
-def _worker(rank, world, port, t, q):
+def test_paired_blocks_rule(orc, tmp_path):
+    """-p -t 2: mate block k appended to block k; outputs split back by the block-1 read count."""
+    f1, f2 = paired_inputs(str(tmp_path))
+    eng = util.OracleEngine(orc, m=5)
+    names = parallel.output_names([f1, f2], str(tmp_path / "OUT"), True)
+    parallel.run_files(eng, parallel.Comm(), [f1, f2], 2, names, paired=True)
+    assert md5file(names[0]["fastq"]) == MD5_P1 and md5file(names[1]["fastq"]) == MD5_P2
+
+
+def _streams_of(fq_text, in_text):
+    lines = fq_text.split(b"\n")[:-1]
+    return (b"".join(x + b"\n" for x in lines[1::4]), b"".join(x + b"\n" for x in lines[3::4]),
+            b"".join(x + b"\n" for x in in_text.split(b"\n")[:-1][0::4]))
+
+
+def check_streams(names, inputs):
+    for nm, inp in zip(names, inputs):
+        fq = open(nm["fastq"], "rb").read()
+        dna, qs, hdr = _streams_of(fq, open(inp, "rb").read())
+        assert open(nm["dna"], "rb").read() == dna and open(nm["qs"], "rb").read() == qs
+        assert open(nm["hdr"], "rb").read() == hdr
+        assert fq.split(b"\n")[:-1][0::4] == hdr.split(b"\n")[:-1]              # --m3 keeps the header lines
+
+
+def _worker(rank, world, port, mode, t, tmp, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from oracle import orc
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    b, qq, r, h, *_ = util.golden_set("example")
-    res = parallel.run_blocks(_oracle_block(orc), b, qq, r, t, dist=dist)
-    if rank == 0:
-        q.put(hashlib.md5(fastq.format_fastq(res[0], res[1], r)).hexdigest())
-    else:
-        assert res is None
-    dist.barrier()
-    dist.destroy_process_group()
+    comm = parallel.Comm(dist)
+    eng = util.OracleEngine(orc, m=5)
+    try:
+        if mode == "single":
+            names = parallel.output_names([EXAMPLE], os.path.join(tmp, "OUT"), False)
+            parallel.run_files(eng, comm, [EXAMPLE], t, names)
+            res = md5file(names[0]["fastq"])
+        elif mode == "m3":
+            names = parallel.output_names([EXAMPLE], os.path.join(tmp, "OUT"), False)
+            parallel.run_files(eng, comm, [EXAMPLE], t, names, headers=True, want_streams=True, want_hdr=True)
+            if rank == 0:
+                check_streams(names, [EXAMPLE])
+            res = "ok"
+        else:
+            f1, f2 = os.path.join(tmp, "r1.fastq"), os.path.join(tmp, "r2.fastq")
+            names = parallel.output_names([f1, f2], os.path.join(tmp, "OUT"), True)
+            hdrs = mode == "paired_m3"
+            parallel.run_files(eng, comm, [f1, f2], t, names, paired=True, headers=hdrs, want_streams=hdrs, want_hdr=hdrs)
+            if hdrs and rank == 0:
+                check_streams(names, [f1, f2])
+            res = md5file(names[0]["fastq"]) + md5file(names[1]["fastq"])
+        if rank == 0:
+            q.put(res)
+    except Exception as e:                                     # surface the failure instead of a queue timeout
+        q.put(f"rank {rank}: {type(e).__name__}: {e}")
+        raise
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("t,md5", [(2, "d2aac3c45dda67ec3f769273ea6a5568"), (8, "4ada980195fd8d6fb206408c4f892bc6")])
-def test_two_ranks_gloo(t, md5):
+def _run2(mode, t, tmp):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + t
-    ps = [ctx.Process(target=_worker, args=(rk, 2, port, t, q)) for rk in range(2)]
+    port = 29500 + (os.getpid() * 7 + t + len(mode) * 13) % 3000
+    ps = [ctx.Process(target=_worker, args=(rk, 2, port, mode, t, tmp, q)) for rk in range(2)]
     for p in ps:
         p.start()
-    got = q.get(timeout=120)
+    got = q.get(timeout=180)
     for p in ps:
         p.join(timeout=60)
-        assert p.exitcode == 0
-    assert got == md5
+        assert p.exitcode == 0, got
+    return got
+
+
+@pytest.mark.parametrize("t", [2, 8])
+def test_two_ranks_gloo(t, tmp_path):
+    assert _run2("single", t, str(tmp_path)) == MD5[t]
+
+
+def test_two_ranks_gloo_streams_and_headers(tmp_path):
+    assert _run2("m3", 8, str(tmp_path)) == "ok"
+
+
+def test_two_ranks_gloo_paired(tmp_path):
+    paired_inputs(str(tmp_path))
+    assert _run2("paired", 2, str(tmp_path)) == MD5_P1 + MD5_P2
+    # headers + streams in paired mode: bases / qualities are those of the header-less run, header lines kept
+    assert _run2("paired_m3", 2, str(tmp_path)) != ""
+    for k, md in ((1, MD5_P1), (2, MD5_P2)):
+        fq = open(str(tmp_path / f"OUT_{k}.fastq"), "rb").read().split(b"\n")[:-1]
+        bare = b"".join((b"@" if i % 4 == 0 else x) + b"\n" for i, x in enumerate(fq))
+        assert hashlib.md5(bare).hexdigest() == md

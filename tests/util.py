@@ -58,3 +58,44 @@ def random_reads(rng, nreads, lmin, lmax, glen=None, p_n=0.05, dup=0.2, qlo=33, 
     roff[1:] = np.cumsum([len(s) for s in reads])
     cat = lambda xs: np.concatenate(xs) if sum(len(x) for x in xs) else np.zeros(0, np.uint8)
     return cat(reads).astype(np.uint8), cat(quals).astype(np.uint8), roff
+
+
+class OracleEngine:
+    """Engine.fastq_job on the CPU oracle: drives bfqzip_amd.parallel in the CPU (gloo) tests, and is the checker the
+    GPU engine's block outputs are compared with."""
+
+    def __init__(self, orc, **params):
+        from bfqzip_amd import api
+        self.orc, self.p = orc, orc.params(**params)
+        self.host = api.HostText
+
+    def fastq_job(self, parts, keep_headers=False, fastq=True, streams=False, hdr=False, out=None):
+        from bfqzip_amd import api, fastq as fqm
+        texts = []
+        for p in parts:
+            b = bytes(np.asarray(p, np.uint8).tobytes()) if not isinstance(p, (bytes, bytearray)) else bytes(p)
+            if b and not b.endswith(b"\n"):
+                b += b"\n"
+            texts.append(b)
+        whole = b"".join(texts)
+        b, q, r, h = fqm.parse_fastq_bytes(whole)
+        ob, oq, st = self.orc.run_reads(b, q, r, self.p)
+        res = api.JobResult()
+        res.n_reads, res.total_bases = len(r) - 1, int(r[-1])
+        res.fastq = np.frombuffer(fqm.format_fastq(ob, oq, r, h if keep_headers else None), np.uint8) if fastq else None
+        res.dna = np.frombuffer(fqm.format_lines(ob, r), np.uint8) if streams else None
+        res.qs = np.frombuffer(fqm.format_lines(oq, r), np.uint8) if streams else None
+        res.hdr = np.frombuffer(fqm.format_headers(h), np.uint8) if hdr else None
+        pr = [0]
+        for t in texts:
+            pr.append(pr[-1] + t.count(b"\n") // 4)
+        hl = h.lengths() if len(h) else np.zeros(0, np.int64)
+        L = np.diff(r.astype(np.int64))
+        fsz = np.concatenate([[0], np.cumsum((hl if keep_headers else np.ones(len(L), np.int64)) + 2 * L + 5)])
+        hsz = np.concatenate([[0], np.cumsum(hl + 1)])
+        res.part_reads = pr
+        res.part_fastq_off = [int(fsz[i]) for i in pr] if fastq else [0] * len(pr)
+        res.part_stream_off = [int(r[i]) + i for i in pr] if streams else [0] * len(pr)
+        res.part_hdr_off = [int(hsz[i]) for i in pr] if hdr else [0] * len(pr)
+        res.stats = dict(st)
+        return res
