@@ -18,7 +18,7 @@ SYMBOLS = [
     "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_fastq_run_streams",
     "bfq_smooth_invert_fastq", "bfq_fastq_run_job", "bfq_host_alloc", "bfq_host_free",
     "bfq_text_count_lines", "bfq_text_nth_newline",
-    "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device",
+    "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device", "bfq_synth_fastq",
     "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
     "bfq_workspace_bytes", "bfq_version",
 ]
@@ -43,7 +43,7 @@ class Synth(C.Structure):
     _fields_ = [("seed", C.c_uint64), ("N", C.c_uint64), ("Lmin", C.c_uint32), ("Lmax", C.c_uint32),
                 ("coverage", C.c_uint32), ("err_ppm", C.c_uint32), ("n_ppm", C.c_uint32),
                 ("snp_every", C.c_uint32), ("dsnp_every", C.c_uint32), ("both_strands", C.c_uint32),
-                ("reserved", C.c_uint32 * 5)]
+                ("first", C.c_uint64), ("collection", C.c_uint64), ("reserved", C.c_uint32 * 2)]
 
 
 MAX_PARTS = 4
@@ -124,6 +124,7 @@ def lib():
         L.bfq_synth_total.argtypes = [C.POINTER(Synth)]
         L.bfq_synth_host.argtypes = [C.POINTER(Synth), vp, vp, vp]
         L.bfq_synth_device.argtypes = [vp, C.POINTER(Synth), vp, vp, vp]
+        L.bfq_synth_fastq.argtypes = [vp, C.POINTER(Synth), vp, u64, C.POINTER(u64)]
         L.bfq_prof_enable.argtypes = [vp, C.c_int]
         L.bfq_prof_reset.argtypes = [vp]
         L.bfq_prof_count.argtypes = [vp]

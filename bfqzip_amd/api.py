@@ -128,7 +128,8 @@ class Engine:
         return bwt, qs, lcp
 
     # ---- steps 2-4
-    def smooth_invert(self, bwt, qs, lcp=None):
+    def smooth_invert(self, bwt, qs, lcp=None, out=None):
+        """out: optional (bases u8[n-N], quals u8[n-N], roff u64[N+1]) arrays to fill (e.g. pinned)."""
         bwt = np.ascontiguousarray(bwt, np.uint8); qs = np.ascontiguousarray(qs, np.uint8)
         n = len(bwt)
         N = C.c_uint64(0)
@@ -138,12 +139,16 @@ class Engine:
         if lcp is not None:
             lcp = np.ascontiguousarray(lcp)
             lcp_bytes = lcp.dtype.itemsize
-        ob = np.empty(max(n - N, 1), np.uint8); oq = np.empty(max(n - N, 1), np.uint8)
-        oroff = np.empty(N + 1, np.uint64)
+        if out is not None:
+            ob, oq, oroff = out
+            assert len(ob) >= n - N and len(oq) >= n - N and len(oroff) >= N + 1 and oroff.dtype == np.uint64
+        else:
+            ob = np.empty(max(n - N, 1), np.uint8); oq = np.empty(max(n - N, 1), np.uint8)
+            oroff = np.empty(N + 1, np.uint64)
         st = _lib.Stats()
         self._ck(self.L.bfq_smooth_invert(self.h, _ptr(bwt), _ptr(qs), _ptr(lcp), lcp_bytes, n,
                                           _ptr(ob), _ptr(oq), _ptr(oroff), C.byref(st)))
-        return ob[:n - N], oq[:n - N], oroff, st.as_dict()
+        return ob[:n - N], oq[:n - N], oroff[:N + 1], st.as_dict()
 
     # ---- fused
     def run_reads(self, bases, quals, roff):
@@ -216,10 +221,8 @@ class Engine:
         def buf(key, want, size):
             if not want:
                 return None
-            b = out.get(key)
-            if b is None or len(b) < size:
-                b = np.empty(size, np.uint8)
-            return b
+            b = out.get(key)                      # a caller's buffer is used as it is (too small: BFQ_E_ARG)
+            return b if b is not None else np.empty(size, np.uint8)
         J = _lib.FastqJob()
         J.parts = tp; J.nparts = np_; J.keep_headers = 1 if keep_headers else 0
         bf = buf("fastq", fastq, inlen + 5 * np_ + 16)
@@ -265,14 +268,20 @@ class Engine:
                                                 len(hb) if hb is not None else 0, _ptr(out), cap, C.byref(ol), C.byref(st)))
         return out[:ol.value].tobytes(), st.as_dict()
 
-    def fetch_ebwt(self, n):
-        bwt = np.empty(n, np.uint8); qs = np.empty(n, np.uint8); lcp = np.empty(n, np.uint16)
+    def fetch_ebwt(self, n, out=None):
+        bwt, qs, lcp = out if out is not None else (np.empty(n, np.uint8), np.empty(n, np.uint8), np.empty(n, np.uint16))
         self._ck(self.L.bfq_fetch_ebwt(self.h, _ptr(bwt), _ptr(qs), _ptr(lcp)))
         return bwt, qs, lcp
 
     # ---- synthetic reads
     def synth_device(self, spec, d_bases, d_quals, d_roff):
         self._ck(self.L.bfq_synth_device(self.h, C.byref(spec), d_bases, d_quals, d_roff))
+
+    def synth_fastq(self, spec, out):
+        """The synthetic reads of `spec` as FASTQ text (headers "@SYN.<n>") into the uint8 array `out`; returns the length."""
+        ol = C.c_uint64(0)
+        self._ck(self.L.bfq_synth_fastq(self.h, C.byref(spec), _ptr(out), len(out), C.byref(ol)))
+        return int(ol.value)
 
     # ---- profiling
     def prof_reset(self):

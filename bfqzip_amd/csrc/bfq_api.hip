@@ -16,7 +16,7 @@
 const char *const BFQ_KERNEL_NAMES[K_NUM] = {
     "k_text_from_reads", "k_pack3", "k_build_keys", "k_radix_hist", "k_scan", "k_radix_scatter", "k_huge_round",
     "k_cluster_big", "k_refine_chunk", "k_refine_big", "k_emit_bwt", "k_lf_count", "k_lf_build", "k_lcp_flags",
-    "k_cluster", "k_invert_count", "k_invert", "k_synth", "k_fastq", "misc"};
+    "k_cluster", "k_invert_count", "k_invert", "k_synth", "k_fastq", "k_bfs", "misc"};
 
 static thread_local std::string g_createErr;
 
@@ -248,6 +248,18 @@ static size_t ws_need(u64 n, u64 N, u64 extra)
     return need;
 }
 
+// the same for steps 2-4 on a given eBWT: eBWT + qualities + reads out (4 n), LCP (2 n), LF table (8 n), flags (n);
+// the interval refinement's rank blocks and queue (9 n) live where the LF table and the flags come afterwards
+static size_t ws_need_given(u64 n, u64 N, u64 extra)
+{
+    size_t need = 0;
+    need += 6 * (n + 256) + 4096;
+    need += 10 * (n + 1024) + 72 * (n / 256 + 2);
+    need += 16 * (N + 64) + (n >> 20) * 64 + 4096;
+    need += extra + (64u << 20);
+    return need;
+}
+
 // ---------------------------------------------------------------- step 1
 void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,
                       int termOut, bfq_stats *st)
@@ -280,13 +292,24 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
 }
 
 // ---------------------------------------------------------------- steps 2-4
-static void steps234_device(bfq_ctx *c, const u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals)
+// lens != nullptr: the read lengths are not known (an eBWT given from outside): they are counted by LF walks on the
+// table before the clusters edit it, d_roff (N + 1 entries) receives the offsets; the walks must cover the eBWT.
+static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals, u32 *lens = nullptr)
 {
     u64 n = c->n, N = c->N;
     if (!n) return;
     // the symbol counts of step 1's emission are reused when this eBWT is the one it just wrote
     const u32 *gc = (c->d_gcnt && c->gcntTerm == (c->P.term & 0xFF)) ? c->d_gcnt : nullptr;
     RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term, gc);
+    if (lens) {
+        bfq_invert_count(c, R, N, lens);
+        bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
+        u64 tot2 = 0;
+        HIP_CHECK(hipMemcpyAsync(&tot2, d_roff + N, 8, hipMemcpyDeviceToHost, c->stream));
+        c->fetchCounters();
+        check_counters(c);
+        if (tot2 != n - N) throw BfqError{BFQ_E_NOT_EBWT, "LF walks do not cover the eBWT"};
+    }
     u8 *in = c->alloc<u8>(n + 64);
     bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
     bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n);
@@ -302,7 +325,7 @@ extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const ui
         c->reserve(ws_need(total + N, N, 0));
         c->zeroCounters();
         bfq_step1_device(c, d_bases, d_quals, (const u64 *)d_read_off, N, total, c->P.term, st);
-        steps234_device(c, (const u64 *)d_read_off, d_out_bases, d_out_quals);
+        steps234_device(c, (u64 *)d_read_off, d_out_bases, d_out_quals);
         c->fetchCounters();
         c->profCollect();
         check_counters(c);
@@ -378,14 +401,6 @@ __global__ __launch_bounds__(256) void k_lcp_widen(const u8 *__restrict__ raw, i
     }
 }
 
-__global__ __launch_bounds__(256) void k_compare_bytes(const u8 *__restrict__ a, const u8 *__restrict__ b, u64 n,
-                                                       DevCounters *cnt)
-{
-    bool bad = false;
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) bad |= (a[i] != b[i]);
-    if (bad) atomicAdd(&cnt->mismatch, 1ull);
-}
-
 // steps 2-4 on a host-resident eBWT; leaves the smoothed reads on the device (arena)
 struct SmoothOut { u8 *ob, *oq; u64 *roff; u64 N, total; };
 static void smooth_invert_core(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp, int lcp_bytes,
@@ -400,7 +415,7 @@ static void smooth_invert_core(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *
         u64 N = Nr;
         if (n && N == 0) throw BfqError{BFQ_E_NOT_EBWT, "no terminator in the eBWT"};
         u64 total = n - N;
-        c->reserve(ws_need(n, N, 10 * (n + 256) + 16 * (N + 64) + extraWs));
+        c->reserve(ws_need_given(n, N, extraWs + (h_lcp ? (size_t)lcp_bytes * n : 0)));
         c->zeroCounters();
         u8 *in_bwt = c->alloc<u8>(n + 64), *in_qs = c->alloc<u8>(n + 64);
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
@@ -408,48 +423,22 @@ static void smooth_invert_core(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *
         u32 *lens = c->alloc<u32>(N + 1);
         bfq_upload(c, in_bwt, h_bwt, n);
         bfq_upload(c, in_qs, h_bwtqs, n);
+        // the persistent arrays hold the given eBWT directly
+        c->n = n; c->N = N;
+        c->d_bwt = in_bwt; c->d_qual = in_qs;
+        c->d_lcp = c->alloc<u16>(n + 64);
         if (h_lcp) {
-            // explicit LCP (bfq_ext): persistent arrays hold the given eBWT directly
-            c->n = n; c->N = N;
-            c->d_bwt = in_bwt; c->d_qual = in_qs;
-            c->d_lcp = c->alloc<u16>(n + 64);
-            {   // the file's entries (1, 2 or 4 bytes) are widened / clamped to 16 bits on the device
-                size_t mr = c->mark();
-                u8 *raw = c->alloc<u8>((size_t)lcp_bytes * n + 64);
-                bfq_upload(c, raw, h_lcp, (size_t)lcp_bytes * n);
-                KLAUNCH(c, K_MISC, (double)(lcp_bytes + 2) * (double)n, k_lcp_widen, bfq_grid(n, 256), 256, (const u8 *)raw, lcp_bytes, n, c->d_lcp);
-                c->release(mr);
-            }
-            size_t m = c->mark();
-            RankIndex R0 = bfq_rank_build(c, in_bwt, in_qs, n, c->P.term);
-            bfq_invert_count(c, R0, N, lens);
-            bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
-            c->release(m);
+            // explicit LCP (bfq_ext): the file's entries (1, 2 or 4 bytes) are widened / clamped to 16 bits on the device
+            size_t mr = c->mark();
+            u8 *raw = c->alloc<u8>((size_t)lcp_bytes * n + 64);
+            bfq_upload(c, raw, h_lcp, (size_t)lcp_bytes * n);
+            KLAUNCH(c, K_MISC, (double)(lcp_bytes + 2) * (double)n, k_lcp_widen, bfq_grid(n, 256), 256, (const u8 *)raw, lcp_bytes, n, c->d_lcp);
+            c->release(mr);
         } else {
-            // bfq_int deduces the LCP from the BWT (bfq_int.cpp:183-300): here by inverting
-            // the eBWT and rebuilding it with step 1, which also yields the LCP array
-            size_t m = c->mark();
-            u8 *rb = c->alloc<u8>(total + 64), *rq = c->alloc<u8>(total + 64);
-            {
-                size_t m2 = c->mark();
-                RankIndex R0 = bfq_rank_build(c, in_bwt, in_qs, n, c->P.term);
-                bfq_invert_count(c, R0, N, lens);
-                bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
-                u64 tot2 = 0;
-                HIP_CHECK(hipMemcpyAsync(&tot2, d_roff + N, 8, hipMemcpyDeviceToHost, c->stream));
-                c->fetchCounters();
-                check_counters(c);
-                if (tot2 != total) throw BfqError{BFQ_E_NOT_EBWT, "LF walks do not cover the eBWT"};
-                bfq_invert(c, R0, N, d_roff, 0, rb, rq);
-                c->release(m2);
-            }
-            bfq_step1_device(c, rb, rq, d_roff, N, total, c->P.term, st);
-            KLAUNCH(c, K_MISC, 2.0 * (double)n, k_compare_bytes, bfq_grid(n, 256), 256, (const u8 *)c->d_bwt,
-                    (const u8 *)in_bwt, n, c->d_cnt);
-            HIP_CHECK(hipMemcpyAsync(c->d_qual, in_qs, n, hipMemcpyDeviceToDevice, c->stream));
-            (void)m;   // rb/rq stay allocated below the step-1 arrays; the arena is reset per call
+            // bfq_int deduces the LCP from the BWT alone (detect_minima, bfq_int.cpp:183-300): interval refinement, k_bfs.hip
+            bfq_lcp_from_bwt(c, in_bwt, n, N, c->P.term & 0xFF, c->d_lcp);
         }
-        steps234_device(c, d_roff, ob, oq);
+        steps234_device(c, d_roff, ob, oq, lens);
         res->ob = ob; res->oq = oq; res->roff = d_roff; res->N = N; res->total = total;
     }
 }
@@ -680,7 +669,7 @@ extern "C" uint64_t bfq_synth_total(const bfq_synth *s)
 {
     if (s->Lmin >= s->Lmax) return s->N * (u64)s->Lmin;
     u64 t = 0;
-    for (u64 i = 0; i < s->N; i++) t += bfq_synth_len(s, i);
+    for (u64 i = 0; i < s->N; i++) t += bfq_synth_len(s, s->first + i);
     return t;
 }
 extern "C" int bfq_synth_host(const bfq_synth *s, uint8_t *h_bases, uint8_t *h_quals, uint64_t *h_read_off)
@@ -688,9 +677,9 @@ extern "C" int bfq_synth_host(const bfq_synth *s, uint8_t *h_bases, uint8_t *h_q
     if (!s || !h_read_off) return BFQ_E_ARG;
     u64 o = 0;
     for (u64 i = 0; i < s->N; i++) {
-        u32 len = bfq_synth_len(s, i);
+        u32 len = bfq_synth_len(s, s->first + i);
         h_read_off[i] = o;
-        for (u32 k = 0; k < len; k++) bfq_synth_base(s, i, len, k, h_bases + o + k, h_quals + o + k);
+        for (u32 k = 0; k < len; k++) bfq_synth_base(s, s->first + i, len, k, h_bases + o + k, h_quals + o + k);
         o += len;
     }
     h_read_off[s->N] = o;
@@ -702,6 +691,28 @@ extern "C" int bfq_synth_device(bfq_ctx *c, const bfq_synth *s, uint8_t *d_bases
         if (!s) throw BfqError{BFQ_E_ARG, "null synth spec"};
         c->reserve(16 * (s->N + 4096) + (64u << 20));
         bfq_synth_launch(c, s, d_bases, d_quals, (u64 *)d_read_off);
+        c->sync();
+        c->profCollect();
+    });
+}
+
+u8 *bfq_synth_headers(bfq_ctx *c, const bfq_synth *s, u64 *len);   // k_synth.hip
+extern "C" int bfq_synth_fastq(bfq_ctx *c, const bfq_synth *s, uint8_t *h_out, uint64_t cap, uint64_t *out_len)
+{
+    return guarded(c, [&] {
+        if (!s || !h_out) throw BfqError{BFQ_E_ARG, "null synth spec / output"};
+        const u64 maxTotal = s->N * (u64)s->Lmax;
+        c->reserve(4 * (maxTotal + 4096) + 96 * (s->N + 4096) + (64u << 20));
+        u8 *db = c->alloc<u8>(maxTotal + 64), *dq = c->alloc<u8>(maxTotal + 64);
+        u64 *dr = c->alloc<u64>(s->N + 2);
+        bfq_synth_launch(c, s, db, dq, dr);
+        u64 hl = 0;
+        u8 *hdr = bfq_synth_headers(c, s, &hl);
+        u8 *d_out = nullptr;
+        u64 ol = bfq_fastq_format(c, db, dq, dr, s->N, 1, hdr, hl, nullptr, &d_out);
+        if (out_len) *out_len = ol;
+        if (ol > cap) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text"};
+        bfq_download(c, h_out, d_out, ol);
         c->sync();
         c->profCollect();
     });

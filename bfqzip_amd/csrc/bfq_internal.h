@@ -24,7 +24,7 @@ struct BfqError {
 enum BfqKernel {
     K_TEXT = 0, K_PACK, K_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_HUGE_ROUND, K_CLUSTER_BIG,
     K_REFINE_WAVE, K_REFINE_BIG, K_EMIT, K_RANK_BUILD, K_RANK_FINAL, K_LCP_FLAGS, K_CLUSTER,
-    K_INVERT_COUNT, K_INVERT, K_SYNTH, K_FASTQ, K_MISC, K_NUM
+    K_INVERT_COUNT, K_INVERT, K_SYNTH, K_FASTQ, K_BFS, K_MISC, K_NUM
 };
 extern const char *const BFQ_KERNEL_NAMES[K_NUM];
 
@@ -164,6 +164,8 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
 // steps 2-4 pieces
 RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int term, const u32 *gcnt = nullptr);
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in);
+// LCP array from the eBWT alone (k_bfs.hip): lcp has n + 1 entries
+void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp);
 void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n);
 // LF walks: lengths only, then emission at given offsets
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);

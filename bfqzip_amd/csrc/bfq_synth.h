@@ -7,7 +7,9 @@
 // reads drawn uniformly from either haplotype and (optionally) either strand,
 // substitution errors with low quality, a few 'N' calls with quality '#'.
 // Every byte is a pure function of (seed, read index, offset): any block of
-// reads can be generated independently on any GPU or on the host.
+// reads can be generated independently on any GPU or on the host (bfq_synth.first /
+// .collection: the reads of the spec are reads [first, first+N) of the collection;
+// the functions below take the read's index in the collection).
 #pragma once
 #include "bfq_common.h"
 #include "../../include/bfqzip_hip.h"
@@ -16,7 +18,7 @@ BFQ_HD u64 bfq_synth_genome_len(const bfq_synth *s)
 {
     u64 lavg = ((u64)s->Lmin + s->Lmax) / 2;
     u64 cov = s->coverage ? s->coverage : 1;
-    u64 G = s->N * lavg / cov;
+    u64 G = (s->collection ? s->collection : s->N) * lavg / cov;
     u64 minG = (u64)s->Lmax * 2 + 16;
     return G < minG ? minG : G;
 }

@@ -38,7 +38,7 @@ static void help()
            "-o <arg>    Output fastq (REQUIRED).\n"
            "-k <arg>    Minimum LCP required in clusters. Default: 16.\n"
            "-m <arg>    Minimum length of cluster to be processed. Default: 2.\n"
-           "-v <arg>    Quality score for constant replacement (if M=2). Default: 29.\n"
+           "-v <arg>    Quality score for constant replacement (if M=2). Default: 29.\n"   /* the phred value of the default '>': bfq_int.cpp:122 prints (int)default_value_def - 33 */
            "-f <arg>    Percentage threshold for frequent bases in clusters. Default: 40.\n"
            "-t <arg>    Quality score threshold for trusted bases. Default: 20.\n"
            "-s <arg>    ASCII value of terminator character. Default: 35 (#).\n"
@@ -103,39 +103,39 @@ int main(int argc, char **argv)
     printf("\n\tIllumina 8-level binning: %d\n\tK: %d\n\tm: %d\n\tFrequency threshold: %d%%\n\nOutput fastq file: %s\n\n",
            P.B, P.K, P.m, P.f, output.c_str());
 
-    std::vector<uint8_t> bwt, qs, lcp, hdr;
-    if (!read_file(in_dna, bwt) || !read_file(in_qual, qs)) { fprintf(stderr, "%s: cannot read inputs\n", TOOL); return 1; }
-    if (qs.size() != bwt.size()) { fprintf(stderr, "%s: eBWT and QS lengths differ (bfq_int.cpp:649)\n", TOOL); return 1; }
+    MappedInput bwt, qs, lcp, hdr;
+    if (!bwt.open(in_dna) || !qs.open(in_qual)) { fprintf(stderr, "%s: cannot read inputs\n", TOOL); return 1; }
+    if (qs.size != bwt.size) { fprintf(stderr, "%s: eBWT and QS lengths differ (bfq_int.cpp:649)\n", TOOL); return 1; }
     if (needLcp) {
-        if (!read_file(in_lcp, lcp)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, in_lcp.c_str()); return 1; }
-        if (lcp.size() % (bwt.size() ? bwt.size() : 1) != 0 || (bwt.size() && lcp.size() / bwt.size() != 1 &&
-            lcp.size() / bwt.size() != 2 && lcp.size() / bwt.size() != 4)) {
+        if (!lcp.open(in_lcp)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, in_lcp.c_str()); return 1; }
+        if (lcp.size % (bwt.size ? bwt.size : 1) != 0 || (bwt.size && lcp.size / bwt.size != 1 &&
+            lcp.size / bwt.size != 2 && lcp.size / bwt.size != 4)) {
             fprintf(stderr, "%s: LCP file size does not match the eBWT\n", TOOL); return 1;
         }
     }
-    uint64_t n = bwt.size(), N = 0;
-    bfq_count_reads(bwt.data(), n, P.term, &N);
+    uint64_t n = bwt.size, N = 0;
+    bfq_count_reads(bwt.data, n, P.term, &N);
     printf("Number of reads: %llu\n", (unsigned long long)N);
     bfq_ctx *c = bfq_create(0, &P);
     if (!c) { fprintf(stderr, "%s: %s\n", TOOL, bfq_create_error()); return 1; }
     // the FASTQ text (header line verbatim from -H, else "@"; bases; "+"; qualities -- bfq_int.cpp:797-810)
-    // is laid out on the GPU and written with one fwrite
-    if (headers && !read_file(titles, hdr)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, titles.c_str()); return 1; }
-    uint64_t hdrBytes = 0;
-    if (headers) { hdrBytes = hdr.size(); }
-    uint64_t cap = bfq_fastq_out_bound(n - N, N, headers ? hdrBytes + 1 : 0) + 64, outLen = 0;
-    std::vector<uint8_t> outText(cap);
+    // is laid out on the GPU and lands in a mapping of the output file
+    if (headers && !hdr.open(titles)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, titles.c_str()); return 1; }
+    uint64_t cap = bfq_fastq_out_bound(n - N, N, headers ? hdr.size + 1 : 0) + 64, outLen = 0;
+    MappedOutput outText;
+    if (!outText.open(output, cap)) { perror("invert"); bfq_destroy(c); return 1; }
     bfq_stats st;
-    int lb = (needLcp && n) ? (int)(lcp.size() / n) : 0;
-    int rc = bfq_smooth_invert_fastq(c, bwt.data(), qs.data(), needLcp ? lcp.data() : nullptr, lb, n,
-                                     headers ? hdr.data() : nullptr, hdr.size(), outText.data(), cap, &outLen, &st);
+    int lb = (needLcp && n) ? (int)(lcp.size / n) : 0;
+    int rc = bfq_smooth_invert_fastq(c, bwt.data, qs.data, needLcp ? lcp.data : nullptr, lb, n,
+                                     headers ? (hdr.data ? hdr.data : (const uint8_t *)"") : nullptr, hdr.size, outText.data, cap, &outLen, &st);
     if (rc) {
         fprintf(stderr, "%s: %s\n", TOOL, bfq_last_error(c));
         bfq_destroy(c);
+        outText.close(0);
         return 1;
     }
     bfq_destroy(c);
-    if (!write_file(output, outText.data(), outLen)) { perror("invert"); return 1; }
+    if (!outText.close(outLen)) { perror("invert"); return 1; }
 
     // bfq_int.cpp:1004-1019
     double nb = (double)(n - N), nc = (double)st.num_clust;

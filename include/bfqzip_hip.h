@@ -180,13 +180,18 @@ typedef struct bfq_synth {
     uint32_t snp_every;  /* haplotype SNP period (~1000)            */
     uint32_t dsnp_every; /* adjacent double-SNP period (~10000)     */
     uint32_t both_strands;
-    uint32_t reserved[5];
+    uint64_t first;      /* these N reads are reads [first, first+N) ...                          */
+    uint64_t collection; /* ... of a collection of this many reads (0: N; sets the genome length): */
+    uint32_t reserved[2];/*     a block of BFQzip_parallel's split can be generated on its own     */
 } bfq_synth;
 void bfq_synth_default(bfq_synth *s, uint64_t N, uint32_t L);
 uint64_t bfq_synth_total(const bfq_synth *s);                    /* total bases = read_off[N] */
 int bfq_synth_host(const bfq_synth *s, uint8_t *h_bases, uint8_t *h_quals, uint64_t *h_read_off);
 int bfq_synth_device(bfq_ctx *c, const bfq_synth *s, uint8_t *d_bases, uint8_t *d_quals,
                      uint64_t *d_read_off);
+/* The same reads as the text of a FASTQ file (header lines "@SYN.<read number>", "+" lines bare), generated and
+ * formatted on the device, copied to h_out (cap >= N * (2 * Lmax + 30) is always enough). */
+int bfq_synth_fastq(bfq_ctx *c, const bfq_synth *s, uint8_t *h_out, uint64_t cap, uint64_t *out_len);
 
 /* ---- profiling: per-kernel HIP-event times accumulated over the calls since
  * the last bfq_prof_reset() (events recorded on bfq_stream()). */

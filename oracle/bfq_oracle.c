@@ -379,24 +379,52 @@ int64_t orc_invert(const uint8_t *bwt, const uint8_t *qual, const uint8_t *modbi
 }
 
 /* LCP of a given eBWT.  The reference deduces it from the BWT alone by
- * Weiner-link navigation (bfq_int.cpp:183-300); with distinct terminators
- * that LCP is the LCP of the sorted suffixes, recomputed here directly.     */
+ * Weiner-link navigation (bfq_int.cpp:183-300), seeing ONE terminator symbol: the
+ * result is the LCP of the rows' suffixes with terminators never matching
+ * (bfq_int.cpp:139-145), whatever the order of identical suffixes in the given eBWT.
+ * Here: every row's suffix is located by the LF walks (row -> position in the decoded
+ * reads), then adjacent rows are compared directly.                               */
 int orc_lcp_from_bwt(const uint8_t *bwt, uint64_t n, int term, uint32_t *lcp)
 {
     lfidx lf;
     int rc = lf_build(&lf, bwt, n, term);
     if (rc) return rc;
     uint64_t N = lf.F[1];
-    uint8_t *ob = (uint8_t *)malloc(n + 1), *oq = (uint8_t *)malloc(n + 1);
-    uint64_t *roff = (uint64_t *)malloc(sizeof(uint64_t) * (N + 1));
-    uint8_t *qdummy = (uint8_t *)calloc(n + 1, 1);
-    int64_t r = invert_with_lf(&lf, qdummy, NULL, NULL, 0, ob, oq, roff);
+    uint8_t *T = (uint8_t *)malloc(n + 1);                 /* decoded reads, each followed by a 0 byte */
+    uint64_t *pos = (uint64_t *)malloc(sizeof(uint64_t) * (n ? n : 1));
+    uint64_t *rows = (uint64_t *)malloc(sizeof(uint64_t) * (n + 1));
+    uint64_t o = 0, seen = 0;
+    rc = 0;
+    for (uint64_t i = 0; i < N && !rc; i++) {
+        uint64_t j = i, len = 0;
+        rows[0] = j;
+        while (bwt[j] != (uint8_t)term) {                  /* step t visits the row of the suffix of length t */
+            if (o + len + 1 >= n + 1) { rc = -3; break; }
+            T[o + len] = bwt[j];                           /* back to front, reversed below */
+            len++;
+            j = lf_map(&lf, j);
+            rows[len] = j;
+        }
+        if (rc) break;
+        for (uint64_t a = 0, b = len; a + 1 < b; a++) { b--; uint8_t t = T[o + a]; T[o + a] = T[o + b]; T[o + b] = t; }
+        T[o + len] = 0;
+        for (uint64_t t = 0; t <= len; t++) pos[rows[t]] = o + len - t;
+        seen += len + 1;
+        o += len + 1;
+    }
     free(lf.occ);
-    if (r < 0 || roff[N] + N != n) { free(ob); free(oq); free(roff); free(qdummy); return -4; }
-    uint8_t *b2 = (uint8_t *)malloc(n + 1), *q2 = (uint8_t *)malloc(n + 1);
-    rc = orc_build_ebwt(ob, oq, roff, N, term, b2, q2, lcp, NULL);
-    if (rc == 0 && memcmp(b2, bwt, n) != 0) rc = -5;   /* not an eBWT in #_i<#_j order */
-    free(ob); free(oq); free(roff); free(qdummy); free(b2); free(q2);
+    if (!rc && seen != n) rc = -4;                         /* the walks do not cover the eBWT */
+    if (!rc) {
+        for (uint64_t r = 0; r < n; r++) {
+            uint32_t l = 0;
+            if (r > 0) {
+                const uint8_t *a = T + pos[r - 1], *b = T + pos[r];
+                while (*a && *a == *b) { a++; b++; l++; }  /* terminators never match */
+            }
+            lcp[r] = l;
+        }
+    }
+    free(T); free(pos); free(rows);
     return rc;
 }
 

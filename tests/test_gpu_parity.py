@@ -162,13 +162,81 @@ def test_bfq_ext_arithmetic(engine, orc):
     assert not np.array_equal(iq, gq)
 
 
+def test_bfq_int_mode_any_tie_order(engine, orc):
+    """bfq_int mode deduces the LCP from the BWT alone (k_bfs.hip) and, like the reference (one terminator symbol),
+    takes identical suffixes -- and the terminator rows -- in ANY order: eBWTs with shuffled ties must give what the
+    oracle gives (tests/test_oracle_golden.py pins that behaviour against the compiled reference)."""
+    rng = np.random.default_rng(4321)
+    done = 0
+    for it in range(25):
+        b, q, r = util.random_reads(rng, int(rng.integers(5, 120)), 0 if it % 5 == 0 else 1, int(rng.integers(4, 40)), dup=0.5, p_n=0.02)
+        bwt, qs, lcp = orc.build_ebwt(b, q, r)
+        sb, sq = util.shuffle_ties(bwt, qs, rng)
+        done += int(not np.array_equal(sb, bwt))
+        M, B = int(rng.integers(0, 4)), int(rng.integers(0, 2))
+        k, m = int(rng.choice([1, 2, 3, 5, 8])), int(rng.choice([2, 3, 5]))
+        p = orc.params(K=k, m=m, M=M, B=B)
+        ob, oq, oroff, st = orc.smooth_invert(sb, sq, None, p)
+        engine.set_params(k=k, m=m, M=M, B=B)
+        gb, gq, groff, gst = engine.smooth_invert(sb, sq)
+        assert np.array_equal(gb, ob) and np.array_equal(gq, oq) and np.array_equal(groff, oroff), it
+        for key in st:
+            assert st[key] == gst[key], (it, key)
+    assert done >= 15
+    # blocks of identical suffixes far beyond a wavefront (the fill list), reads that are prefixes of others, empty reads
+    rd = np.frombuffer(b"ACGTTGCAACGTACGTTTGACCAGTACGATCG", np.uint8)
+    reads = [rd] * 700 + [rd[:9]] * 300 + [rd[3:]] * 150 + [np.zeros(0, np.uint8)] * 40 + [rd[::-1].copy()] * 3
+    reads = [reads[i] for i in rng.permutation(len(reads))]
+    b = np.concatenate(reads); q = rng.integers(33, 74, len(b)).astype(np.uint8)
+    r = np.zeros(len(reads) + 1, np.uint64); r[1:] = np.cumsum([len(x) for x in reads])
+    bwt, qs, lcp = orc.build_ebwt(b, q, r)
+    for shuffle in (False, True):
+        sb, sq = util.shuffle_ties(bwt, qs, rng) if shuffle else (bwt, qs)
+        p = orc.params(K=4, m=5)
+        ob, oq, oroff, st = orc.smooth_invert(sb, sq, None, p)
+        engine.set_params(k=4, m=5)
+        gb, gq, groff, gst = engine.smooth_invert(sb, sq)
+        assert np.array_equal(gb, ob) and np.array_equal(gq, oq) and np.array_equal(groff, oroff)
+    engine.set_params()
+
+
+def test_ebwt_modes_config2_size(engine, orc):
+    """BASELINE configs[1] shape (1 M x 100 bp, n = 101 M rows): the eBWT of the fused run handed back in bfq_int mode (LCP
+    deduced from the BWT) and in bfq_ext mode (1-byte LCP file, as eGap --lbytes 1 writes it) against the oracle."""
+    sp = api.synth_spec(1_000_000, 100, seed=20240807)
+    b, q, r = api.synth_host(sp)
+    p = orc.params(m=5)
+    eb, eq, est = orc.run_reads(b, q, r, p)
+    engine.set_params(m=5)
+    gb, gq, gst = engine.run_reads(b, q, r)
+    assert np.array_equal(gb, eb) and np.array_equal(gq, eq)
+    n = len(b) + len(r) - 1
+    bwt, qs, lcp = engine.fetch_ebwt(n)
+    ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)                                   # bfq_int mode
+    assert np.array_equal(ib, eb) and np.array_equal(iq, eq) and np.array_equal(iroff, r)
+    engine.set_params(m=5, ext=1)
+    xb, xq, xroff, xst = engine.smooth_invert(bwt, qs, np.minimum(lcp, 255).astype(np.uint8))   # bfq_ext mode
+    assert np.array_equal(xb, eb) and np.array_equal(xq, eq) and np.array_equal(xroff, r)
+    for k in est:
+        assert est[k] == gst[k] == ist[k], k
+    engine.set_params()
+
+
 def test_full_size_properties(engine):
-    """BASELINE.json configs[2] size (30 M x 150 bp, n = 4.53 G rows) through size-independent properties:
-    K above every LCP -> no cluster -> the output must be the input (sort + LF round trip);
-    default run -> edits are consistent with the statistics and with the M=2 rule."""
+    """BASELINE.json configs[2] size (30 M x 150 bp, n = 4.53 G rows: the only test beyond 2^32 elements) through
+    size-independent properties.  Needs 200 GiB of free HBM: skipped -- visibly -- otherwise.
+      1. K above every LCP -> no cluster -> the output must be the input (sort + LF round trip);
+      2. M=2 B=0: edits consistent with the statistics and with the M=2 rule, deterministic;
+      3. B=1 (configs[2] itself): bases as in 2., qualities = Illumina-binned qualities of 2.;
+      4. M=1 (configs[4]'s smoothing): same base edits and same smoothed positions as 2. (the decision tree does not
+         depend on M), qualities differ only there;
+      5. bfq_int mode (LCP deduced from the eBWT alone) on the 4.53 G-row eBWT of run 2: same reads as run 2."""
     torch = pytest.importorskip("torch")
     free, total = torch.cuda.mem_get_info()
-    N, L = (30_000_000, 150) if free > 200 * 2**30 else (2_000_000, 150)
+    if free < 200 * 2**30:
+        pytest.skip(f"full-size test needs 200 GiB of free HBM, {free / 2**30:.0f} GiB free")
+    N, L = 30_000_000, 150
+    print(f"full-size test: {N} x {L}")
     sp = api.synth_spec(N, L, seed=4242)
     tot = N * L
     dev = torch.device("cuda:0")
@@ -182,7 +250,7 @@ def test_full_size_properties(engine):
     engine.set_params(k=10000, m=5)
     st = run(); torch.cuda.synchronize()
     assert st["num_clust"] == 0 and st["n_rows"] == tot + N and st["n_reads"] == N
-    assert torch.equal(ob, db) and torch.equal(oq, dq)                      # identity round trip
+    assert torch.equal(ob, db) and torch.equal(oq, dq)                      # 1. identity round trip
     engine.set_params(k=16, m=5, M=2, B=0, v=ord(">"))
     st = run(); torch.cuda.synchronize()
     changed_b = ob != db
@@ -193,9 +261,44 @@ def test_full_size_properties(engine):
     assert not bool((changed_b & changed_q).any())                         # a replaced base keeps its quality
     assert bool(((ob == ord("N")) <= (db == ord("N"))).all())              # N is never written
     st2 = run(); torch.cuda.synchronize()
-    assert st2 == st                                                        # deterministic
-    del db, dq, ob, oq
+    assert st2 == st                                                        # 2. deterministic
+    # 5. bfq_int mode on this run's eBWT (host arrays: the boundary of bfq_smooth_invert)
+    n = tot + N
+    bwt, qs, _ = engine.fetch_ebwt(n)
+    ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)
+    del bwt, qs
+    assert {k: ist[k] for k in ("num_clust", "qs_smoothed", "modified")} == {k: st[k] for k in ("num_clust", "qs_smoothed", "modified")}
+    assert torch.equal(torch.from_numpy(ib).to(dev), ob) and torch.equal(torch.from_numpy(iq).to(dev), oq)
+    assert int(iroff[-1]) == tot and bool((np.diff(iroff.astype(np.int64)) == L).all())
+    del ib, iq, changed_b, changed_q
+    ob2 = ob.clone(); oq2 = oq.clone()
+    # 3. B = 1
+    engine.set_params(k=16, m=5, M=2, B=1, v=ord(">"))
+    stb = run(); torch.cuda.synchronize()
+    assert {k: stb[k] for k in st} == st
+    assert torch.equal(ob, ob2)
+    lut = torch.tensor([_bin8(c) for c in range(256)], dtype=torch.uint8, device=dev)
+    assert torch.equal(oq, lut[oq2.long()])
+    # 4. M = 1
+    engine.set_params(k=16, m=5, M=1, B=0)
+    st1 = run(); torch.cuda.synchronize()
+    assert st1["modified"] == st["modified"] and st1["num_clust"] == st["num_clust"] and st1["num_clust_mod"] == st["num_clust_mod"]
+    assert torch.equal(ob, ob2)
+    ch1 = int((oq != dq).sum().item())
+    assert 0 < ch1 <= st1["qs_smoothed"] and st1["bases_inside"] == st["bases_inside"]
+    assert not bool(((ob != db) & (oq != dq)).any())                       # a replaced base keeps its quality
+    del db, dq, ob, oq, ob2, oq2
     torch.cuda.empty_cache()
+    engine.set_params()
+
+
+def _bin8(c):
+    q = (c - 256 if c > 127 else c) - 33
+    for lo, v in ((40, 40), (35, 37), (30, 33), (25, 27), (20, 22), (10, 15), (2, 6)):
+        if q >= lo:
+            q = v
+            break
+    return (q + 33) & 0xFF
 
 
 def test_long_and_degenerate_collections(engine, orc):

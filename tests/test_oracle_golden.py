@@ -66,3 +66,33 @@ def test_oracle_vs_reference_binary_fuzz(orc):
             p = orc.params(K=K, m=m, v=v, f=f, t=t, M=M, B=B)
             ob, oq, oroff, st = orc.smooth_invert(bwt, qs, None, p)
             assert fastq.format_fastq(ob, oq, oroff) == ref, (it, M, B, K, m, v, t, f)
+
+
+def test_tie_order_of_identical_suffixes_is_free(orc, tmp_path):
+    """The reference sees ONE terminator symbol: an eBWT whose identical suffixes (and terminator rows) are in any
+    order is processed all the same, LCP by the usual convention.  Pins, against the compiled reference, the contract the
+    GPU's BWT-only LCP deduction (k_bfs.hip) is tested with in tests/test_gpu_parity.py."""
+    import subprocess
+    ref = orc.ref_binary(2, 0)
+    if ref is None:
+        pytest.skip("reference bfq_int not built (oracle/_ref)")
+    rng = np.random.default_rng(99)
+    done = 0
+    for it in range(12):
+        b, q, r = util.random_reads(rng, int(rng.integers(5, 60)), 1, int(rng.integers(4, 40)), dup=0.45, p_n=0.02)
+        bwt, qs, lcp = orc.build_ebwt(b, q, r)
+        sb, sq = util.shuffle_ties(bwt, qs, rng)
+        if np.array_equal(sb, bwt):
+            continue
+        suf, reads = util.decode_rows(sb)
+        lc = util.lcp_of_rows(suf)
+        p = orc.params(m=2, K=int(rng.choice([2, 3, 5])))
+        ob, oq, oroff, st = orc.smooth_invert(sb, sq, lc, p)
+        ob2, oq2, oroff2, st2 = orc.smooth_invert(sb, sq, None, p)            # the oracle's own BWT-only deduction
+        assert np.array_equal(ob, ob2) and np.array_equal(oq, oq2) and st == st2
+        sb.tofile(str(tmp_path / "x.bwt")); sq.tofile(str(tmp_path / "x.bwt.qs"))
+        subprocess.check_call([ref, "-e", str(tmp_path / "x.bwt"), "-q", str(tmp_path / "x.bwt.qs"), "-o", str(tmp_path / "o.fq"),
+                               "-m", "2", "-k", str(p.K)], stdout=subprocess.DEVNULL)
+        assert open(str(tmp_path / "o.fq"), "rb").read() == fastq.format_fastq(ob, oq, oroff)
+        done += 1
+    assert done >= 6

@@ -99,3 +99,60 @@ class OracleEngine:
         res.part_hdr_off = [int(hsz[i]) for i in pr] if hdr else [0] * len(pr)
         res.stats = dict(st)
         return res
+
+
+def decode_rows(bwt, term=ord("#")):
+    """For every row of an eBWT: (read index, suffix start) found by the LF walks, plus the reads (small inputs only).
+    Returns (suffix strings per row as bytes, reads as list of bytes)."""
+    bwt = np.asarray(bwt, np.uint8)
+    n = len(bwt)
+    order = [term] + [ord(c) for c in "ACGNT"]
+    F, acc = {}, 0
+    for c in order:
+        F[c] = acc; acc += int(np.count_nonzero(bwt == c))
+    occ = {c: 0 for c in order}
+    LF = np.zeros(n, np.int64)
+    for r in range(n):
+        c = int(bwt[r]); LF[r] = F[c] + occ[c]; occ[c] += 1
+    N = F[ord("A")]
+    suf = [None] * n
+    reads = []
+    for i in range(N):
+        r, s = i, b""
+        while True:
+            suf[r] = s
+            if bwt[r] == term:
+                break
+            s = bytes([bwt[r]]) + s; r = int(LF[r])
+        reads.append(s)
+    return suf, reads
+
+
+def shuffle_ties(bwt, qs, rng):
+    """Permute the rows of every block of identical suffixes independently: an eBWT of the same kind (one terminator
+    symbol, decodable) whose ties are in no consistent order -- what another step-1 tool may produce."""
+    suf, _ = decode_rows(bwt)
+    bwt, qs = np.array(bwt, np.uint8), np.array(qs, np.uint8)
+    j, n = 0, len(bwt)
+    while j < n:
+        e = j
+        while e < n and suf[e] == suf[j]:
+            e += 1
+        if e - j > 1:
+            p = rng.permutation(e - j) + j
+            bwt[j:e] = bwt[p]; qs[j:e] = qs[p]
+        j = e
+    return bwt, qs
+
+
+def lcp_of_rows(suf):
+    """LCP array by the convention of bfq_int.cpp:139-145 / bfq_ext.cpp:377-392 from decoded suffixes (terminators never match)."""
+    n = len(suf)
+    L = np.zeros(n, np.uint32)
+    for r in range(1, n):
+        a, b = suf[r - 1], suf[r]
+        k = 0
+        while k < len(a) and k < len(b) and a[k] == b[k]:
+            k += 1
+        L[r] = k
+    return L
