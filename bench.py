@@ -127,16 +127,22 @@ def e2e_host(api, eng, sp, N, L, iters, log):
     return out, pin, tlen, outs
 
 
-def ebwt_modes(api, eng, N, L, log):
-    """The step 2-4 tools on the eBWT of the last run, host arrays in / host arrays out (pinned): bfq_int mode (LCP deduced
-    from the BWT alone, k_bfs.hip) and bfq_ext mode (LCP given, 2 bytes per entry)."""
+def ebwt_modes(api, eng, text, N, L, log):
+    """The reference's tool boundary in process, host arrays (pinned) in and out: step 1 alone (gsufsort / eGap: FASTQ text ->
+    eBWT, QS, LCP), then steps 2-4 on that eBWT in bfq_int mode (LCP deduced from the BWT alone, k_bfs.hip) and in bfq_ext
+    mode (LCP given, 2 bytes per entry)."""
     n = N * (L + 1)
     pins = [api.PinnedBuffer(n), api.PinnedBuffer(n), api.PinnedBuffer(2 * n), api.PinnedBuffer(N * L), api.PinnedBuffer(N * L), api.PinnedBuffer(8 * (N + 1))]
     bwt, qs = pins[0].array, pins[1].array
     lcp = pins[2].array.view(np.uint16)
-    eng.fetch_ebwt(n, out=(bwt, qs, lcp))
     out = (pins[3].array, pins[4].array, pins[5].array.view(np.uint64))
     res = {}
+    eng.fastq_build_ebwt(text, out=(bwt, qs, lcp))
+    t0 = time.perf_counter()
+    eng.fastq_build_ebwt(text, out=(bwt, qs, lcp))
+    dt = time.perf_counter() - t0
+    res["build_ebwt"] = {"wall_ms": round(dt * 1e3, 1), "Mbases_per_s": round(N * L / 1e6 / dt, 1)}
+    log(f"build_ebwt (gsufsort / eGap boundary): {dt * 1e3:.0f} ms")
     for name, l in (("bfq_int", None), ("bfq_ext", lcp)):
         eng.smooth_invert(bwt, qs, l, out=out)                      # warm-up: sizes the workspace
         eng.prof_reset()
@@ -150,7 +156,9 @@ def ebwt_modes(api, eng, N, L, log):
         log(f"{name} mode: {dt * 1e3:.0f} ms")
     for p in pins:
         p.free()
-    res["what"] = "bfq_smooth_invert on host (pinned) eBWT arrays -> host reads: upload, [LCP from the BWT | LCP upload], LF table, clusters, two LF walks (lengths, reads), download"
+    res["what"] = ("build_ebwt: bfq_fastq_build_ebwt, FASTQ text -> eBWT + QS + 2-byte LCP (pinned host arrays); bfq_int / bfq_ext: "
+                   "bfq_smooth_invert on those arrays -> host reads: upload, [LCP from the BWT | LCP upload], LF table, clusters, "
+                   "two LF walks (lengths, reads), download")
     return res
 
 
@@ -341,7 +349,7 @@ def main():
                 try:
                     for v in outs.values():
                         v.free()
-                    res["ebwt_modes"] = ebwt_modes(api, eng, Nw, L, log)
+                    res["ebwt_modes"] = ebwt_modes(api, eng, text, Nw, L, log)
                 except Exception as e:
                     res["ebwt_modes"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_cpu:

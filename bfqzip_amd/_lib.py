@@ -17,7 +17,7 @@ SYMBOLS = [
     "bfq_smooth_invert", "bfq_run_reads", "bfq_run_reads_device", "bfq_fetch_ebwt",
     "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_fastq_run_streams",
     "bfq_smooth_invert_fastq", "bfq_fastq_run_job", "bfq_host_alloc", "bfq_host_free",
-    "bfq_text_count_lines", "bfq_text_nth_newline",
+    "bfq_text_count_lines", "bfq_text_nth_newline", "bfq_fastq_build_ebwt_fd", "bfq_smooth_invert_fastq_fd",
     "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device", "bfq_synth_fastq",
     "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
     "bfq_workspace_bytes", "bfq_version",

@@ -169,12 +169,17 @@ class Engine:
         return st.as_dict()
 
     # ---- FASTQ text in / out, parsed and formatted on the GPU
-    def fastq_build_ebwt(self, text, term_out=ord("#"), want_lcp=True):
-        """gsufsort / eGap on the bytes of a FASTQ file -> (bwt, qs, lcp16)."""
-        buf = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
-        cap = len(buf) // 2 + 1
-        bwt = np.empty(cap, np.uint8); qs = np.empty(cap, np.uint8)
-        lcp = np.empty(cap, np.uint16) if want_lcp else None
+    def fastq_build_ebwt(self, text, term_out=ord("#"), want_lcp=True, out=None):
+        """gsufsort / eGap on the bytes of a FASTQ file -> (bwt, qs, lcp16).  out: optional (bwt, qs, lcp16 or None) arrays."""
+        buf = _u8(text)
+        if out is not None:
+            bwt, qs, lcp = out
+            cap = min(len(bwt), len(qs), len(lcp) if lcp is not None else len(bwt))
+            want_lcp = lcp is not None
+        else:
+            cap = len(buf) // 2 + 1
+            bwt = np.empty(cap, np.uint8); qs = np.empty(cap, np.uint8)
+            lcp = np.empty(cap, np.uint16) if want_lcp else None
         n = C.c_uint64(0); N = C.c_uint64(0)
         self._ck(self.L.bfq_fastq_build_ebwt(self.h, _ptr(buf), len(buf), term_out, _ptr(bwt), _ptr(qs), _ptr(lcp), cap,
                                              C.byref(n), C.byref(N)))

@@ -9,9 +9,11 @@
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
+#include <unistd.h>
 #include <new>
 #include "bfq_internal.h"
 #include "bfq_synth.h"
+#include "bfq_device.h"
 
 const char *const BFQ_KERNEL_NAMES[K_NUM] = {
     "k_text_from_reads", "k_pack3", "k_build_keys", "k_radix_hist", "k_scan", "k_radix_scatter", "k_huge_round",
@@ -292,28 +294,45 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
 }
 
 // ---------------------------------------------------------------- steps 2-4
-// lens != nullptr: the read lengths are not known (an eBWT given from outside): they are counted by LF walks on the
-// table before the clusters edit it, d_roff (N + 1 entries) receives the offsets; the walks must cover the eBWT.
+// lens != nullptr: the read lengths are not known (an eBWT given from outside).  Collections of equal-length reads
+// (n - N a multiple of N) are first inverted on that assumption -- k_invert checks every walk against its slot, so a
+// wrong guess is noticed -- which saves the counting walk; otherwise, or when the guess fails, the lengths are counted
+// by LF walks and d_roff (N + 1 entries) receives their offsets; the walks must cover the eBWT.
+static void count_lengths(bfq_ctx *c, const RankIndex &R, u64 *d_roff, u32 *lens)
+{
+    const u64 n = c->n, N = c->N;
+    bfq_invert_count(c, R, N, lens);
+    bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
+    u64 tot2 = 0;
+    HIP_CHECK(hipMemcpyAsync(&tot2, d_roff + N, 8, hipMemcpyDeviceToHost, c->stream));
+    c->fetchCounters();
+    check_counters(c);
+    if (tot2 != n - N) throw BfqError{BFQ_E_NOT_EBWT, "LF walks do not cover the eBWT"};
+}
 static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals, u32 *lens = nullptr)
 {
     u64 n = c->n, N = c->N;
     if (!n) return;
-    // the symbol counts of step 1's emission are reused when this eBWT is the one it just wrote
+    // the symbol counts of step 1's emission (or of the interval refinement) are reused when they belong to this eBWT
     const u32 *gc = (c->d_gcnt && c->gcntTerm == (c->P.term & 0xFF)) ? c->d_gcnt : nullptr;
     RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term, gc);
+    bool guessed = false;
     if (lens) {
-        bfq_invert_count(c, R, N, lens);
-        bfq_exscan_u32(c, lens, d_roff, N, d_roff + N);
-        u64 tot2 = 0;
-        HIP_CHECK(hipMemcpyAsync(&tot2, d_roff + N, 8, hipMemcpyDeviceToHost, c->stream));
-        c->fetchCounters();
-        check_counters(c);
-        if (tot2 != n - N) throw BfqError{BFQ_E_NOT_EBWT, "LF walks do not cover the eBWT"};
+        if (N && (n - N) % N == 0 && !getenv("BFQ_NO_LENGTH_GUESS")) { bfq_fixed_offsets(c, N, (n - N) / N, d_roff); guessed = true; }
+        else count_lengths(c, R, d_roff, lens);
     }
     u8 *in = c->alloc<u8>(n + 64);
     bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
     bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n);
     bfq_invert(c, R, N, d_roff, c->P.B, d_out_bases, d_out_quals);
+    if (guessed) {
+        c->fetchCounters();
+        if (c->h_cnt.errInvert) {                              // not all of one length after all: count, then walk again
+            HIP_CHECK(hipMemsetAsync(&c->d_cnt->errInvert, 0, sizeof(u64), c->stream));
+            count_lengths(c, R, d_roff, lens);
+            bfq_invert(c, R, N, d_roff, c->P.B, d_out_bases, d_out_quals);
+        }
+    }
 }
 
 extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_quals,
@@ -401,33 +420,56 @@ __global__ __launch_bounds__(256) void k_lcp_widen(const u8 *__restrict__ raw, i
     }
 }
 
-// steps 2-4 on a host-resident eBWT; leaves the smoothed reads on the device (arena)
+__global__ __launch_bounds__(256) void k_count_byte(const u8 *__restrict__ a, u64 n, u32 v, u64 *out)
+{
+    u64 k = 0;
+    const u64 n16 = n / 16;                                       // the buffer is 16-byte aligned
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (u64)gridDim.x * blockDim.x) {
+        const uint4 x = ((const uint4 *)a)[i];
+        const u32 w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) k += (((w[q] >> (8 * b)) & 0xFFu) == v);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 15)) k += (a[n16 * 16 + threadIdx.x] == (u8)v);
+    k = bfq_readlane64(bfq_wave_incscan64(k), 63);
+    if ((threadIdx.x & 63) == 0 && k) atomicAdd((unsigned long long *)out, (unsigned long long)k);
+}
+
+// steps 2-4 on an eBWT given by the caller (host memory or files); leaves the smoothed reads on the device (arena).
+// The eBWT and its qualities are uploaded into the context's text buffer (outside the arena), the terminators are
+// counted there, and only then is the arena sized.
 struct SmoothOut { u8 *ob, *oq; u64 *roff; u64 N, total; };
-static void smooth_invert_core(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp, int lcp_bytes,
+static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostRef h_lcp, int lcp_bytes,
                                uint64_t n, size_t extraWs, bfq_stats *st, SmoothOut *res)
 {
     {
         if (st) memset(st, 0, sizeof *st);
-        if (n && (!h_bwt || !h_bwtqs)) throw BfqError{BFQ_E_ARG, "null eBWT"};
-        if (h_lcp && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
-        uint64_t Nr = 0;
-        bfq_count_reads(h_bwt, n, c->P.term & 0xFF, &Nr);
-        u64 N = Nr;
+        if (n && (h_bwt.null() || h_bwtqs.null())) throw BfqError{BFQ_E_ARG, "null eBWT"};
+        const bool haveLcp = !h_lcp.null();
+        if (haveLcp && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
+        const u64 npad = (n + 255) & ~255ull;
+        u8 *in_bwt = c->textBuf(2 * npad + 256), *in_qs = in_bwt + npad;
+        bfq_upload(c, in_bwt, h_bwt, n);
+        c->zeroCounters();
+        if (n) KLAUNCH(c, K_MISC, (double)n, k_count_byte, bfq_grid(n / 16 + 1, 256), 256, (const u8 *)in_bwt, n, (u32)(c->P.term & 0xFF), &c->d_cnt->pad[0]);
+        c->fetchCounters();
+        const u64 N = c->h_cnt.pad[0];
         if (n && N == 0) throw BfqError{BFQ_E_NOT_EBWT, "no terminator in the eBWT"};
         u64 total = n - N;
-        c->reserve(ws_need_given(n, N, extraWs + (h_lcp ? (size_t)lcp_bytes * n : 0)));
-        c->zeroCounters();
-        u8 *in_bwt = c->alloc<u8>(n + 64), *in_qs = c->alloc<u8>(n + 64);
+        c->reserve(ws_need_given(n, N, extraWs + (haveLcp ? (size_t)lcp_bytes * n : 0)));
+        bfq_upload(c, in_qs, h_bwtqs, n);
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
         u64 *d_roff = c->alloc<u64>(N + 1);
         u32 *lens = c->alloc<u32>(N + 1);
-        bfq_upload(c, in_bwt, h_bwt, n);
-        bfq_upload(c, in_qs, h_bwtqs, n);
         // the persistent arrays hold the given eBWT directly
         c->n = n; c->N = N;
         c->d_bwt = in_bwt; c->d_qual = in_qs;
         c->d_lcp = c->alloc<u16>(n + 64);
-        if (h_lcp) {
+        c->d_gcnt = c->alloc<u32>(6 * (n / 256 + 1));
+        c->gcntTerm = -1;
+        if (haveLcp) {
             // explicit LCP (bfq_ext): the file's entries (1, 2 or 4 bytes) are widened / clamped to 16 bits on the device
             size_t mr = c->mark();
             u8 *raw = c->alloc<u8>((size_t)lcp_bytes * n + 64);
@@ -436,7 +478,8 @@ static void smooth_invert_core(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *
             c->release(mr);
         } else {
             // bfq_int deduces the LCP from the BWT alone (detect_minima, bfq_int.cpp:183-300): interval refinement, k_bfs.hip
-            bfq_lcp_from_bwt(c, in_bwt, n, N, c->P.term & 0xFF, c->d_lcp);
+            bfq_lcp_from_bwt(c, in_bwt, n, N, c->P.term & 0xFF, c->d_lcp, c->d_gcnt);
+            c->gcntTerm = c->P.term & 0xFF;
         }
         steps234_device(c, d_roff, ob, oq, lens);
         res->ob = ob; res->oq = oq; res->roff = d_roff; res->N = N; res->total = total;
@@ -449,7 +492,7 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
 {
     return guarded(c, [&] {
         SmoothOut r;
-        smooth_invert_core(c, h_bwt, h_bwtqs, h_lcp, lcp_bytes, n, 0, st, &r);
+        smooth_invert_core(c, HostRef::mem(h_bwt), HostRef::mem(h_bwtqs), HostRef::mem(h_lcp), lcp_bytes, n, 0, st, &r);
         bfq_download(c, h_out_bases, r.ob, r.total);
         bfq_download(c, h_out_quals, r.oq, r.total);
         bfq_download(c, h_out_read_off, r.roff, 8 * (r.N + 1));
@@ -481,21 +524,30 @@ u8 *bfq_ctx::textBuf(size_t bytes)
 
 // Uploads the parts back to back (a part that does not end in '\n' gets one, so that no record straddles two
 // parts); pstart[p] = offset of part p in the device text, pstart[nparts] = its length.
-static u8 *fastq_upload_and_reserve(bfq_ctx *c, const bfq_text_part *parts, int nparts, std::vector<u64> &pstart)
+struct TextSrc { HostRef ref; u64 len; };
+static bool src_ends_with_newline(const TextSrc &t)
+{
+    if (!t.len) return true;
+    if (t.ref.ptr) return ((const u8 *)t.ref.ptr)[t.len - 1] == (u8)'\n';
+    u8 b = 0;
+    if (pread(t.ref.fd, &b, 1, (off_t)(t.ref.off + t.len - 1)) != 1) throw BfqError{BFQ_E_IO, "cannot read the input file"};
+    return b == (u8)'\n';
+}
+static u8 *fastq_upload_and_reserve(bfq_ctx *c, const TextSrc *parts, int nparts, std::vector<u64> &pstart)
 {
     pstart.assign(nparts + 1, 0);
     std::vector<u8> addNl(nparts, 0);
     u64 len = 0;
     for (int p = 0; p < nparts; p++) {
-        if (parts[p].len && !parts[p].data) throw BfqError{BFQ_E_ARG, "null FASTQ text"};
+        if (parts[p].len && parts[p].ref.null()) throw BfqError{BFQ_E_ARG, "null FASTQ text"};
         pstart[p] = len;
         len += parts[p].len;
-        if (parts[p].len && parts[p].data[parts[p].len - 1] != (u8)'\n') { addNl[p] = 1; len++; }
+        if (!src_ends_with_newline(parts[p])) { addNl[p] = 1; len++; }
     }
     pstart[nparts] = len;
     u8 *d_fq = c->textBuf(len + 64);
     for (int p = 0; p < nparts; p++) {
-        bfq_upload(c, d_fq + pstart[p], parts[p].data, parts[p].len);
+        bfq_upload(c, d_fq + pstart[p], parts[p].ref, parts[p].len);
         if (addNl[p]) HIP_CHECK(hipMemsetAsync(d_fq + pstart[p] + parts[p].len, '\n', 1, c->stream));
     }
     c->reserve(16 * (len / 4096 + 16) + (64u << 20));
@@ -511,28 +563,62 @@ extern "C" uint64_t bfq_fastq_out_bound(uint64_t total_bases, uint64_t n_reads, 
     return 2 * total_bases + 5 * n_reads + (header_bytes ? header_bytes : n_reads);
 }
 
+__global__ __launch_bounds__(256) void k_lcp_narrow(const u16 *__restrict__ lcp, int lb, u64 n, u8 *__restrict__ raw)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) {
+        const u32 v = lcp[i];
+        if (lb == 1) raw[i] = (u8)(v > 255u ? 255u : v);         // eGap --lbytes 1 saturates
+        else ((u32 *)raw)[i] = v;
+    }
+}
+
+static void fastq_build_ebwt_core(bfq_ctx *c, TextSrc text, int term_out, HostRef bwt, HostRef qs, HostRef lcp, int lcp_bytes,
+                                  uint64_t cap_rows, uint64_t *n_rows, uint64_t *n_reads)
+{
+    if (!lcp.null() && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
+    std::vector<u64> ps;
+    u8 *d_fq = fastq_upload_and_reserve(c, &text, 1, ps);
+    c->zeroCounters();
+    DevFastq fq;
+    bfq_fastq_parse(c, d_fq, ps[1], &fq);
+    u64 n = fq.total + fq.N;
+    if (n_rows) *n_rows = n;
+    if (n_reads) *n_reads = fq.N;
+    if (n > cap_rows) throw BfqError{BFQ_E_ARG, "output buffers smaller than the eBWT (need total bases + reads entries)"};
+    bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, term_out, nullptr);
+    if (!bwt.null()) bfq_download(c, bwt, c->d_bwt, n);
+    if (!qs.null()) bfq_download(c, qs, c->d_qual, n);
+    if (!lcp.null()) {
+        if (lcp_bytes == 2) bfq_download(c, lcp, c->d_lcp, 2 * n);
+        else {
+            u8 *raw = c->alloc<u8>((size_t)lcp_bytes * n + 64);
+            if (n) KLAUNCH(c, K_MISC, (double)(lcp_bytes + 2) * (double)n, k_lcp_narrow, bfq_grid(n, 256), 256, (const u16 *)c->d_lcp, lcp_bytes, n, raw);
+            bfq_download(c, lcp, raw, (size_t)lcp_bytes * n);
+        }
+    }
+    c->fetchCounters();
+    c->profCollect();
+    check_counters(c);
+}
+
 extern "C" int bfq_fastq_build_ebwt(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int term_out, uint8_t *h_bwt,
                                     uint8_t *h_bwtqs, uint16_t *h_lcp16, uint64_t cap_rows, uint64_t *n_rows,
                                     uint64_t *n_reads)
 {
     return guarded(c, [&] {
-        bfq_text_part part{h_fastq, len};
-        std::vector<u64> ps;
-        u8 *d_fq = fastq_upload_and_reserve(c, &part, 1, ps);
-        c->zeroCounters();
-        DevFastq fq;
-        bfq_fastq_parse(c, d_fq, ps[1], &fq);
-        u64 n = fq.total + fq.N;
-        if (n_rows) *n_rows = n;
-        if (n_reads) *n_reads = fq.N;
-        if (n > cap_rows) throw BfqError{BFQ_E_ARG, "output buffers smaller than the eBWT (need total bases + reads entries)"};
-        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, term_out, nullptr);
-        if (h_bwt) bfq_download(c, h_bwt, c->d_bwt, n);
-        if (h_bwtqs) bfq_download(c, h_bwtqs, c->d_qual, n);
-        if (h_lcp16) bfq_download(c, h_lcp16, c->d_lcp, 2 * n);
-        c->fetchCounters();
-        c->profCollect();
-        check_counters(c);
+        fastq_build_ebwt_core(c, TextSrc{HostRef::mem(h_fastq), len}, term_out, HostRef::mem(h_bwt), HostRef::mem(h_bwtqs), HostRef::mem(h_lcp16), 2,
+                              cap_rows, n_rows, n_reads);
+    });
+}
+
+extern "C" int bfq_fastq_build_ebwt_fd(bfq_ctx *c, int fastq_fd, uint64_t len, int term_out, int bwt_fd, int bwtqs_fd, int lcp_fd,
+                                       int lcp_bytes, uint64_t *n_rows, uint64_t *n_reads)
+{
+    return guarded(c, [&] {
+        if (fastq_fd < 0) throw BfqError{BFQ_E_ARG, "bad file descriptor"};
+        fastq_build_ebwt_core(c, TextSrc{HostRef::file(fastq_fd), len}, term_out, bwt_fd >= 0 ? HostRef::file(bwt_fd) : HostRef(),
+                              bwtqs_fd >= 0 ? HostRef::file(bwtqs_fd) : HostRef(), lcp_fd >= 0 ? HostRef::file(lcp_fd) : HostRef(), lcp_bytes,
+                              ~0ull, n_rows, n_reads);
     });
 }
 
@@ -547,7 +633,9 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         const int np = J->nparts;
         J->fastq_len = J->stream_len = J->hdr_len = J->n_reads = J->total_bases = 0;
         std::vector<u64> ps;
-        u8 *d_fq = fastq_upload_and_reserve(c, J->parts, np, ps);
+        TextSrc src[BFQ_MAX_PARTS];
+        for (int p = 0; p < np; p++) src[p] = TextSrc{HostRef::mem(J->parts[p].data), J->parts[p].len};
+        u8 *d_fq = fastq_upload_and_reserve(c, src, np, ps);
         const u64 len = ps[np];
         c->zeroCounters();
         DevFastq fq;
@@ -560,7 +648,8 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         size_t m = c->mark();
         bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
         steps234_device(c, fq.roff, ob, oq);
-        c->release(m);                                         // the formatted text may reuse the pipeline's space
+        c->release(m);                                         // the formatted text may reuse the pipeline's space:
+        c->d_bwt = c->d_qual = nullptr; c->d_lcp = nullptr; c->d_gcnt = nullptr;   // the eBWT is gone (bfq_fetch_ebwt refuses)
         std::vector<u64> hp(4 * (np + 1), 0);
         bool pickF = false, pickS = false, pickH = false;
         HIP_CHECK(hipMemcpyAsync(hp.data(), d_pidx, 8 * (np + 1), hipMemcpyDeviceToHost, c->stream));
@@ -634,27 +723,45 @@ extern "C" int bfq_fastq_run_streams(bfq_ctx *c, const uint8_t *h_fastq, uint64_
     return rc;
 }
 
+static void smooth_invert_fastq_core(bfq_ctx *c, HostRef bwt, HostRef qs, HostRef lcp, int lcp_bytes, uint64_t n, HostRef headers,
+                                     bool haveHeaders, uint64_t headers_len, HostRef out, uint64_t cap, uint64_t *out_len, bfq_stats *st)
+{
+    SmoothOut r;
+    smooth_invert_core(c, bwt, qs, lcp, lcp_bytes, n, 3 * (n + 4096) + 2 * headers_len + (32u << 20), st, &r);
+    u8 *d_hdr = nullptr;
+    if (haveHeaders) {
+        d_hdr = c->alloc<u8>(headers_len + 64);
+        bfq_upload(c, d_hdr, headers, headers_len);
+    }
+    u8 *d_out = nullptr;
+    u64 ol = bfq_fastq_format(c, r.ob, r.oq, r.roff, r.N, haveHeaders ? 1 : 0, d_hdr, headers_len, nullptr, &d_out);
+    if (out_len) *out_len = ol;
+    if (ol > cap) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
+    bfq_download(c, out, d_out, ol);
+    c->fetchCounters();
+    c->profCollect();
+    check_counters(c);
+    fill_stats(c, st);
+}
+
 extern "C" int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_bwtqs, const void *h_lcp,
                                        int lcp_bytes, uint64_t n, const uint8_t *h_headers, uint64_t headers_len,
                                        uint8_t *h_out, uint64_t cap, uint64_t *out_len, bfq_stats *st)
 {
     return guarded(c, [&] {
-        SmoothOut r;
-        smooth_invert_core(c, h_bwt, h_bwtqs, h_lcp, lcp_bytes, n, 3 * (n + 4096) + 2 * headers_len + (32u << 20), st, &r);
-        u8 *d_hdr = nullptr;
-        if (h_headers) {
-            d_hdr = c->alloc<u8>(headers_len + 64);
-            bfq_upload(c, d_hdr, h_headers, headers_len);
-        }
-        u8 *d_out = nullptr;
-        u64 ol = bfq_fastq_format(c, r.ob, r.oq, r.roff, r.N, h_headers ? 1 : 0, d_hdr, headers_len, nullptr, &d_out);
-        if (out_len) *out_len = ol;
-        if (ol > cap) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
-        bfq_download(c, h_out, d_out, ol);
-        c->fetchCounters();
-        c->profCollect();
-        check_counters(c);
-        fill_stats(c, st);
+        smooth_invert_fastq_core(c, HostRef::mem(h_bwt), HostRef::mem(h_bwtqs), HostRef::mem(h_lcp), lcp_bytes, n, HostRef::mem(h_headers),
+                                 h_headers != nullptr, headers_len, HostRef::mem(h_out), cap, out_len, st);
+    });
+}
+
+extern "C" int bfq_smooth_invert_fastq_fd(bfq_ctx *c, int bwt_fd, int qs_fd, int lcp_fd, int lcp_bytes, uint64_t n, int headers_fd,
+                                          uint64_t headers_len, int out_fd, uint64_t *out_len, bfq_stats *st)
+{
+    return guarded(c, [&] {
+        if (bwt_fd < 0 || qs_fd < 0 || out_fd < 0) throw BfqError{BFQ_E_ARG, "bad file descriptor"};
+        smooth_invert_fastq_core(c, HostRef::file(bwt_fd), HostRef::file(qs_fd), lcp_fd >= 0 ? HostRef::file(lcp_fd) : HostRef(), lcp_bytes, n,
+                                 headers_fd >= 0 ? HostRef::file(headers_fd) : HostRef(), headers_fd >= 0, headers_len, HostRef::file(out_fd),
+                                 ~0ull, out_len, st);
     });
 }
 

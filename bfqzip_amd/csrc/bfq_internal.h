@@ -113,6 +113,15 @@ struct bfq_ctx {
     size_t textCap = 0;
     u8 *textBuf(size_t bytes);
 };
+// a host-side operand of a transfer: memory, or an open file at an offset (the front-ends' files)
+struct HostRef {
+    void *ptr = nullptr; int fd = -1; u64 off = 0;
+    static HostRef mem(const void *p) { HostRef h; h.ptr = const_cast<void *>(p); return h; }
+    static HostRef file(int fd, u64 off = 0) { HostRef h; h.fd = fd; h.off = off; return h; }
+    bool null() const { return !ptr && fd < 0; }
+};
+void bfq_upload(bfq_ctx *c, void *d_dst, HostRef src, size_t len);
+void bfq_download(bfq_ctx *c, HostRef dst, const void *d_src, size_t len);
 void bfq_upload(bfq_ctx *c, void *d_dst, const void *h_src, size_t len);
 void bfq_download(bfq_ctx *c, void *h_dst, const void *d_src, size_t len);
 
@@ -165,10 +174,11 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
 RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int term, const u32 *gcnt = nullptr);
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in);
 // LCP array from the eBWT alone (k_bfs.hip): lcp has n + 1 entries
-void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp);
+void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp, u32 *gcntOut = nullptr);   // gcntOut: [6][n/256+1] symbol counts, kept
 void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n);
 // LF walks: lengths only, then emission at given offsets
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);
+void bfq_fixed_offsets(bfq_ctx *c, u64 N, u64 L, u64 *d_roff);   // d_roff[i] = i * L, i <= N
 void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals);
 
 void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, u64 *d_roff);

@@ -14,8 +14,11 @@
 // parsing it (one sharded pass over the bytes).
 #include <string.h>
 #include <stdlib.h>
+#include <unistd.h>
+#include <errno.h>
 #include <thread>
 #include <algorithm>
+#include <atomic>
 #include "bfq_internal.h"
 
 static int io_threads()
@@ -73,8 +76,35 @@ void bfq_ctx::ioFree()
     ioWorkers = 0;
 }
 
+// host side of a staged chunk: memory, or a file at an offset (pread / pwrite: the kernel copies between the page
+// cache and the pinned staging buffer, no mapping, no page faults in user space)
+static bool host_get(const HostRef &h, size_t off, char *dst, size_t sz)
+{
+    if (h.ptr) { memcpy(dst, (const char *)h.ptr + off, sz); return true; }
+    size_t got = 0;
+    while (got < sz) {
+        ssize_t r = pread(h.fd, dst + got, sz - got, (off_t)(h.off + off + got));
+        if (r < 0 && errno == EINTR) continue;
+        if (r <= 0) return false;
+        got += (size_t)r;
+    }
+    return true;
+}
+static bool host_put(const HostRef &h, size_t off, const char *src, size_t sz)
+{
+    if (h.ptr) { memcpy((char *)h.ptr + off, src, sz); return true; }
+    size_t put = 0;
+    while (put < sz) {
+        ssize_t w = pwrite(h.fd, src + put, sz - put, (off_t)(h.off + off + put));
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) return false;
+        put += (size_t)w;
+    }
+    return true;
+}
+
 // Chunk i of the transfer belongs to worker i mod T.  `up`: host -> device, else device -> host.
-static void staged_copy(bfq_ctx *c, char *dev, char *host, size_t len, bool up)
+static void staged_copy(bfq_ctx *c, char *dev, HostRef host, size_t len, bool up)
 {
     c->ioInit();
     const int T = c->ioWorkers;
@@ -82,6 +112,7 @@ static void staged_copy(bfq_ctx *c, char *dev, char *host, size_t len, bool up)
     const size_t nch = (len + CH - 1) / CH;
     hipError_t errs[BFQ_IO_MAX_WORKERS];
     for (int t = 0; t < T; t++) errs[t] = hipSuccess;
+    std::atomic<bool> ioFail{false};
     auto work = [&](int t) {
         bfq_ctx::IoWorker &w = c->io[t];
         hipError_t e = hipSetDevice(c->device);
@@ -94,7 +125,7 @@ static void staged_copy(bfq_ctx *c, char *dev, char *host, size_t len, bool up)
                 // previous chunk's DMA (issued from stage[k^1]) is not needed -- only stage[k]'s own
                 if (i >= (size_t)(2 * T)) e = hipEventSynchronize(w.done[k]);
                 if (e != hipSuccess) break;
-                memcpy(w.stage[k], host + off, sz);
+                if (!host_get(host, off, w.stage[k], sz)) { ioFail = true; break; }
                 e = hipMemcpyAsync(dev + off, w.stage[k], sz, hipMemcpyHostToDevice, w.stream);
                 if (e == hipSuccess) e = hipEventRecord(w.done[k], w.stream);
             } else {
@@ -102,7 +133,7 @@ static void staged_copy(bfq_ctx *c, char *dev, char *host, size_t len, bool up)
                 if (e == hipSuccess) e = hipEventRecord(w.done[k], w.stream);
                 if (pend[k ^ 1]) {                               // while that DMA runs: drain the other buffer
                     if (e == hipSuccess) e = hipEventSynchronize(w.done[k ^ 1]);
-                    if (e == hipSuccess) memcpy(host + poff[k ^ 1], w.stage[k ^ 1], pend[k ^ 1]);
+                    if (e == hipSuccess && !host_put(host, poff[k ^ 1], w.stage[k ^ 1], pend[k ^ 1])) ioFail = true;
                     pend[k ^ 1] = 0;
                 }
                 pend[k] = sz; poff[k] = off;
@@ -111,7 +142,7 @@ static void staged_copy(bfq_ctx *c, char *dev, char *host, size_t len, bool up)
         if (e == hipSuccess) e = hipStreamSynchronize(w.stream);
         if (!up && e == hipSuccess)
             for (int q = 0; q < 2; q++)
-                if (pend[q]) memcpy(host + poff[q], w.stage[q], pend[q]);
+                if (pend[q] && !host_put(host, poff[q], w.stage[q], pend[q])) ioFail = true;
         errs[t] = e;
     };
     for (int t = 0; t < T; t++)
@@ -123,32 +154,35 @@ static void staged_copy(bfq_ctx *c, char *dev, char *host, size_t len, bool up)
     for (auto &x : th) x.join();
     for (int t = 0; t < T; t++)
         if (errs[t] != hipSuccess) throw BfqError{BFQ_E_HIP, std::string("staged transfer: ") + hipGetErrorString(errs[t])};
+    if (ioFail) throw BfqError{BFQ_E_IO, std::string("staged transfer: file read / write failed: ") + strerror(errno)};
 }
 
 // host -> device.  Ordered after everything already on the context's stream; when it returns the
 // data is either on the device (staged path) or queued on the context's stream (pinned source).
-void bfq_upload(bfq_ctx *c, void *d_dst, const void *h_src, size_t len)
+void bfq_upload(bfq_ctx *c, void *d_dst, HostRef src, size_t len)
 {
     if (!len) return;
-    if (is_pinned(h_src) || len < (1u << 20)) {
-        HIP_CHECK(hipMemcpyAsync(d_dst, h_src, len, hipMemcpyHostToDevice, c->stream));
+    if (src.ptr && (is_pinned(src.ptr) || len < (1u << 20))) {
+        HIP_CHECK(hipMemcpyAsync(d_dst, src.ptr, len, hipMemcpyHostToDevice, c->stream));
         return;
     }
     c->sync();                                          // d_dst may still be in use by queued kernels
-    staged_copy(c, (char *)d_dst, (char *)h_src, len, true);
+    staged_copy(c, (char *)d_dst, src, len, true);
 }
+void bfq_upload(bfq_ctx *c, void *d_dst, const void *h_src, size_t len) { bfq_upload(c, d_dst, HostRef::mem(h_src), len); }
 
 // device -> host, same rules; with a pageable destination the call returns with the bytes in place
-void bfq_download(bfq_ctx *c, void *h_dst, const void *d_src, size_t len)
+void bfq_download(bfq_ctx *c, HostRef dst, const void *d_src, size_t len)
 {
     if (!len) return;
-    if (is_pinned(h_dst) || len < (1u << 20)) {
-        HIP_CHECK(hipMemcpyAsync(h_dst, d_src, len, hipMemcpyDeviceToHost, c->stream));
+    if (dst.ptr && (is_pinned(dst.ptr) || len < (1u << 20))) {
+        HIP_CHECK(hipMemcpyAsync(dst.ptr, d_src, len, hipMemcpyDeviceToHost, c->stream));
         return;
     }
     c->sync();                                          // the producer kernels run on the context's stream
-    staged_copy(c, (char *)d_src, (char *)h_dst, len, false);
+    staged_copy(c, (char *)d_src, dst, len, false);
 }
+void bfq_download(bfq_ctx *c, void *h_dst, const void *d_src, size_t len) { bfq_download(c, HostRef::mem(h_dst), d_src, len); }
 
 // ---------------------------------------------------------------- host-side line index
 // counts[i] = number of '\n' in bytes [i*chunk, (i+1)*chunk) of the text

@@ -103,7 +103,7 @@ int main(int argc, char **argv)
     printf("\n\tIllumina 8-level binning: %d\n\tK: %d\n\tm: %d\n\tFrequency threshold: %d%%\n\nOutput fastq file: %s\n\n",
            P.B, P.K, P.m, P.f, output.c_str());
 
-    MappedInput bwt, qs, lcp, hdr;
+    InFile bwt, qs, lcp, hdr;
     if (!bwt.open(in_dna) || !qs.open(in_qual)) { fprintf(stderr, "%s: cannot read inputs\n", TOOL); return 1; }
     if (qs.size != bwt.size) { fprintf(stderr, "%s: eBWT and QS lengths differ (bfq_int.cpp:649)\n", TOOL); return 1; }
     if (needLcp) {
@@ -113,29 +113,27 @@ int main(int argc, char **argv)
             fprintf(stderr, "%s: LCP file size does not match the eBWT\n", TOOL); return 1;
         }
     }
-    uint64_t n = bwt.size, N = 0;
-    bfq_count_reads(bwt.data, n, P.term, &N);
-    printf("Number of reads: %llu\n", (unsigned long long)N);
+    uint64_t n = bwt.size;
     bfq_ctx *c = bfq_create(0, &P);
     if (!c) { fprintf(stderr, "%s: %s\n", TOOL, bfq_create_error()); return 1; }
     // the FASTQ text (header line verbatim from -H, else "@"; bases; "+"; qualities -- bfq_int.cpp:797-810)
-    // is laid out on the GPU and lands in a mapping of the output file
+    // is laid out on the GPU and written straight from the library's staging buffers
     if (headers && !hdr.open(titles)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, titles.c_str()); return 1; }
-    uint64_t cap = bfq_fastq_out_bound(n - N, N, headers ? hdr.size + 1 : 0) + 64, outLen = 0;
-    MappedOutput outText;
-    if (!outText.open(output, cap)) { perror("invert"); bfq_destroy(c); return 1; }
+    OutFile outText;
+    if (!outText.open(output)) { perror("invert"); bfq_destroy(c); return 1; }
+    uint64_t outLen = 0;
     bfq_stats st;
     int lb = (needLcp && n) ? (int)(lcp.size / n) : 0;
-    int rc = bfq_smooth_invert_fastq(c, bwt.data, qs.data, needLcp ? lcp.data : nullptr, lb, n,
-                                     headers ? (hdr.data ? hdr.data : (const uint8_t *)"") : nullptr, hdr.size, outText.data, cap, &outLen, &st);
+    int rc = bfq_smooth_invert_fastq_fd(c, bwt.fd, qs.fd, needLcp ? lcp.fd : -1, lb, n, headers ? hdr.fd : -1, hdr.size, outText.fd, &outLen, &st);
     if (rc) {
         fprintf(stderr, "%s: %s\n", TOOL, bfq_last_error(c));
         bfq_destroy(c);
-        outText.close(0);
         return 1;
     }
     bfq_destroy(c);
-    if (!outText.close(outLen)) { perror("invert"); return 1; }
+    if (!outText.close()) { perror("invert"); return 1; }
+    const uint64_t N = st.n_reads;
+    printf("Number of reads: %llu\n", (unsigned long long)N);
 
     // bfq_int.cpp:1004-1019
     double nb = (double)(n - N), nc = (double)st.num_clust;

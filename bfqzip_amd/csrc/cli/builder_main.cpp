@@ -30,30 +30,22 @@ int main(int argc, char **argv)
     if (in.empty()) { fprintf(stderr, "%s: no input FASTQ\n", tool); return 1; }
     if (out.empty()) out = in;
     if (lbytes != 1 && lbytes != 2 && lbytes != 4) { fprintf(stderr, "%s: --lbytes must be 1, 2 or 4\n", tool); return 1; }
-    // the file's bytes go to the GPU as they are (mapped, staged by the library): records are indexed, split and
-    // sorted there; the outputs are written through mappings of the output files
-    MappedInput buf;
+    // the file's bytes go to the GPU as they are (read into pinned staging by the library): records are indexed,
+    // split and sorted there; the outputs are written straight from the staging buffers
+    InFile buf;
     if (!buf.open(in)) { fprintf(stderr, "%s: cannot read %s\n", tool, in.c_str()); return 1; }
     bfq_ctx *c = bfq_create(0, nullptr);
     if (!c) { fprintf(stderr, "%s: %s\n", tool, bfq_create_error()); return 1; }
-    uint64_t cap = buf.size / 2 + 1, n = 0, N = 0;
-    MappedOutput bwt, qs, lcpf;
-    std::string lp = out + "." + std::to_string(lbytes) + ".lcp";
-    bool ok = bwt.open(out + ".bwt", cap) && qs.open(out + ".bwt.qs", cap);
-    std::unique_ptr<uint16_t[]> lcp16;
-    uint16_t *lcp = nullptr;
-    if (ok && wantLcp) {
-        if (lbytes == 2) { ok = lcpf.open(lp, 2 * cap); lcp = (uint16_t *)lcpf.data; }
-        else { lcp16.reset(new (std::nothrow) uint16_t[cap]); lcp = lcp16.get(); ok = lcp != nullptr && lcpf.open(lp, (size_t)lbytes * cap); }
-    }
+    uint64_t n = 0, N = 0;
+    OutFile bwt, qs, lcpf;
+    bool ok = bwt.open(out + ".bwt") && qs.open(out + ".bwt.qs");
+    if (ok && wantLcp) ok = lcpf.open(out + "." + std::to_string(lbytes) + ".lcp");
     if (!ok) { fprintf(stderr, "%s: cannot create outputs for %s\n", tool, out.c_str()); bfq_destroy(c); return 1; }
-    int rc = bfq_fastq_build_ebwt(c, buf.data, buf.size, term, bwt.data, qs.data, lcp, cap, &n, &N);
+    int rc = bfq_fastq_build_ebwt_fd(c, buf.fd, buf.size, term, bwt.fd, qs.fd, wantLcp ? lcpf.fd : -1, lbytes, &n, &N);
     if (rc) { fprintf(stderr, "%s: %s: %s\n", tool, in.c_str(), bfq_last_error(c)); bfq_destroy(c); return 1; }
     bfq_destroy(c);
-    if (wantLcp && lbytes == 1) { uint8_t *l8 = lcpf.data; for (uint64_t i = 0; i < n; i++) l8[i] = lcp[i] > 255 ? 255 : (uint8_t)lcp[i]; }
-    if (wantLcp && lbytes == 4) { uint32_t *l32 = (uint32_t *)lcpf.data; for (uint64_t i = 0; i < n; i++) l32[i] = lcp[i]; }
-    ok = bwt.close(n) && qs.close(n);
-    if (wantLcp) ok = lcpf.close((size_t)lbytes * n) && ok;
+    ok = bwt.close() && qs.close();
+    ok = lcpf.close() && ok;
     if (!ok) { fprintf(stderr, "%s: cannot write outputs for %s\n", tool, out.c_str()); return 1; }
     printf("%s (bfqzip_amd/gfx950): %llu reads, %llu eBWT symbols -> %s.bwt, %s.bwt.qs%s\n", tool, (unsigned long long)N,
            (unsigned long long)n, out.c_str(), out.c_str(), wantLcp ? " (+lcp)" : "");

@@ -87,25 +87,41 @@ __global__ __launch_bounds__(256) void k_rankblocks(const u8 *__restrict__ bwt, 
     if (bad) atomicAdd(&cnt->errSymbol, 1ull);
 }
 
-// occurrences of the codes 1..5 in rows [0, p)
-__device__ __forceinline__ void occ5(const u64 *__restrict__ rank, u64 p, u64 *o)
+// one rank block in registers; random blocks are read past the L1 (nontemporal: a block is used once per level)
+struct RankBlk { u64 w[8]; };
+__device__ __forceinline__ RankBlk load_blk(const u64 *__restrict__ rank, u64 blk)
 {
-    const ulonglong2 *b = (const ulonglong2 *)(rank + ((p >> 6) << 3));
-    const ulonglong2 a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3];
+    RankBlk b;
+    const u64 *p = rank + (blk << 3);
+#pragma unroll
+    for (int k = 0; k < 8; k++) b.w[k] = __builtin_nontemporal_load(p + k);
+    return b;
+}
+// occurrences of the codes 1..5 in rows [0, p), p inside (or at the end of) block b
+__device__ __forceinline__ void occ5(const RankBlk &b, u64 p, u64 *o)
+{
     const u32 k = (u32)p & 63u;
     const u64 lo = k ? (~0ull >> (64u - k)) : 0ull;
-    const u64 p0 = a2.y & lo, p1 = a3.x & lo, p2 = a3.y & lo, n0 = ~a2.y & lo, n1 = ~a3.x & lo, n2 = ~a3.y & lo;
-    o[0] = a0.x + (u64)__popcll(p0 & n1 & n2);      // A 001
-    o[1] = a0.y + (u64)__popcll(n0 & p1 & n2);      // C 010
-    o[2] = a1.x + (u64)__popcll(p0 & p1 & n2);      // G 011
-    o[3] = a1.y + (u64)__popcll(n0 & n1 & p2);      // N 100
-    o[4] = a2.x + (u64)__popcll(p0 & n1 & p2);      // T 101
+    const u64 p0 = b.w[5] & lo, p1 = b.w[6] & lo, p2 = b.w[7] & lo, n0 = ~b.w[5] & lo, n1 = ~b.w[6] & lo, n2 = ~b.w[7] & lo;
+    o[0] = b.w[0] + (u64)__popcll(p0 & n1 & n2);      // A 001
+    o[1] = b.w[1] + (u64)__popcll(n0 & p1 & n2);      // C 010
+    o[2] = b.w[2] + (u64)__popcll(p0 & p1 & n2);      // G 011
+    o[3] = b.w[3] + (u64)__popcll(n0 & n1 & p2);      // N 100
+    o[4] = b.w[4] + (u64)__popcll(p0 & n1 & p2);      // T 101
 }
 
 // Extends the intervals of one level.  SIDE: the (few) long intervals of the side list instead of the queue segment.
+#define BQ_STAGE 4096                                        // children staged in LDS per queue reservation
 template <bool SIDE>
 __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend, u32 level, int cur)
 {
+    // The queue tail is ONE address for the whole device: a reservation per wavefront (n / 64 atomics) serialises
+    // there and was 80 % of the kernel.  A workgroup stages its children in LDS over several rounds and reserves
+    // once per ~4000 of them.
+    __shared__ u64 stage[BQ_STAGE];
+    __shared__ u64 sBase;
+    __shared__ u32 scan[4];
+    u32 used = 0;                                                  // uniform: every thread sees the same totals
     const u32 lane = bfq_lane();
     const u64 stride = (u64)gridDim.x * blockDim.x;
     const u64 cnt = SIDE ? a.tail[1 + cur] : qend - qbeg;
@@ -118,37 +134,50 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
         bool leaf = false;
         if (valid) {
             if (SIDE) { lb = a.side[cur][2 * i]; rb = a.side[cur][2 * i + 1]; leaf = (rb & BQ_LEAF) != 0; rb &= ~BQ_LEAF; }
-            else { const u64 e = a.queue[qbeg + i]; lb = e & BQ_LB_MASK; rb = lb + ((e >> BQ_LB_BITS) & BQ_LEN_MAX); leaf = (e & BQ_LEAF) != 0; }
+            else { const u64 e = __builtin_nontemporal_load(a.queue + qbeg + i); lb = e & BQ_LB_MASK; rb = lb + ((e >> BQ_LB_BITS) & BQ_LEN_MAX); leaf = (e & BQ_LEAF) != 0; }
         }
-        u64 ol[5], orr[5];
         u32 nkids = 0;
         u64 kid[5];                                                // packed children to enqueue
         u64 flb = 0, frb = 0;                                      // one pending inline fill per thread: (flb, frb]
         if (valid) {
-            occ5(a.rank, lb, ol);
-            occ5(a.rank, rb + 1, orr);
+            u64 ol[5], orr[5];
+            {
+                const u64 bl = lb >> 6, br = (rb + 1) >> 6;
+                const RankBlk B0 = load_blk(a.rank, bl);
+                occ5(B0, lb, ol);
+                if (br == bl) occ5(B0, rb + 1, orr);               // short intervals: both ends in one block
+                else { const RankBlk B1 = load_blk(a.rank, br); occ5(B1, rb + 1, orr); }
+            }
+            // all boundary probes first (independent loads), then the claims
+            u64 nlb[5], nrb[5];
+            u32 probe[5];
+#pragma unroll
+            for (int c = 0; c < 5; c++) {
+                nlb[c] = a.F[c + 1] + ol[c]; nrb[c] = a.F[c + 1] + orr[c] - 1;
+                probe[c] = (orr[c] > ol[c]) ? (u32)__builtin_nontemporal_load(a.lcp + nrb[c] + 1) : 0u;
+            }
 #pragma unroll
             for (int c = 0; c < 5; c++) {
                 if (orr[c] > ol[c]) {
-                    const u64 nlb = a.F[c + 1] + ol[c], nrb = a.F[c + 1] + orr[c] - 1;
-                    const bool claim = a.lcp[nrb + 1] == LCP_UNSET;
-                    if (claim) { a.lcp[nrb + 1] = (u16)level; written++; }
-                    if (leaf && nrb > nlb) {                       // inner boundaries of the block of identical suffixes
-                        const u64 inner = nrb - nlb;
+                    const bool claim = probe[c] == LCP_UNSET;
+                    if (claim) { a.lcp[nrb[c] + 1] = (u16)level; written++; }
+                    const bool wide = leaf && nrb[c] > nlb[c];
+                    if (wide) {                                    // inner boundaries of the block of identical suffixes
+                        const u64 inner = nrb[c] - nlb[c];
                         written += inner;
-                        if (inner <= 2) { a.lcp[nlb + 1] = (u16)level; a.lcp[nrb] = (u16)level; }
-                        else if (inner <= BQ_FILL_INLINE && frb == flb) { flb = nlb; frb = nrb; }
-                        else if (inner <= BQ_FILL_INLINE) { for (u64 p = nlb + 1; p <= nrb; p++) a.lcp[p] = (u16)level; }   // a second block of the same parent: rare
+                        if (inner <= 2) { a.lcp[nlb[c] + 1] = (u16)level; a.lcp[nrb[c]] = (u16)level; }
+                        else if (inner <= BQ_FILL_INLINE && frb == flb) { flb = nlb[c]; frb = nrb[c]; }
+                        else if (inner <= BQ_FILL_INLINE) { for (u64 p = nlb[c] + 1; p <= nrb[c]; p++) a.lcp[p] = (u16)level; }   // a second block of the same parent: rare
                         else {
                             const u64 k = atomicAdd((unsigned long long *)&a.tail[4], 1ull);
-                            if (k < a.fillCap) { a.fill[2 * k] = nlb; a.fill[2 * k + 1] = nrb; }
+                            if (k < a.fillCap) { a.fill[2 * k] = nlb[c]; a.fill[2 * k + 1] = nrb[c]; }
                         }
                     }
-                    if (claim || (leaf && nrb > nlb)) {
-                        if (nrb - nlb <= BQ_LEN_MAX) kid[nkids++] = nlb | ((nrb - nlb) << BQ_LB_BITS) | (leaf ? BQ_LEAF : 0ull);
+                    if (claim || wide) {
+                        if (nrb[c] - nlb[c] <= BQ_LEN_MAX) kid[nkids++] = nlb[c] | ((nrb[c] - nlb[c]) << BQ_LB_BITS) | (leaf ? BQ_LEAF : 0ull);
                         else {
                             const u64 k = atomicAdd((unsigned long long *)&a.tail[1 + (cur ^ 1)], 1ull);
-                            if (k < a.sideCap) { a.side[cur ^ 1][2 * k] = nlb; a.side[cur ^ 1][2 * k + 1] = nrb | (leaf ? BQ_LEAF : 0ull); }
+                            if (k < a.sideCap) { a.side[cur ^ 1][2 * k] = nlb[c]; a.side[cur ^ 1][2 * k + 1] = nrb[c] | (leaf ? BQ_LEAF : 0ull); }
                         }
                     }
                 }
@@ -160,15 +189,24 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
             const u64 l0 = bfq_readlane64(flb, src), r0 = bfq_readlane64(frb, src);
             if (l0 + 1 + lane <= r0) a.lcp[l0 + 1 + lane] = (u16)level;
         }
-        // one queue reservation per wavefront
-        const u32 incl = bfq_wave_incscan32(nkids);
-        const u32 total = (u32)__builtin_amdgcn_readlane((int)incl, 63);
-        if (total) {
-            u64 base = 0;
-            if (lane == 0) base = atomicAdd((unsigned long long *)&a.tail[0], (unsigned long long)total);
-            base = bfq_readlane64(base, 0) + (incl - nkids);
-            for (u32 k = 0; k < nkids; k++) a.queue[base + k] = kid[k];
+        // children -> LDS stage; flushed with one reservation when the next round might not fit
+        u32 tot;
+        const u32 ex = bfq_block_exscan32(nkids, scan, &tot);
+        if (used + tot > BQ_STAGE) {
+            if (threadIdx.x == 0) sBase = atomicAdd((unsigned long long *)&a.tail[0], (unsigned long long)used);
+            __syncthreads();
+            for (u32 j = threadIdx.x; j < used; j += 256) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+            __syncthreads();
+            used = 0;
         }
+        for (u32 k = 0; k < nkids; k++) stage[used + ex + k] = kid[k];
+        used += tot;
+    }
+    __syncthreads();
+    if (used) {
+        if (threadIdx.x == 0) sBase = atomicAdd((unsigned long long *)&a.tail[0], (unsigned long long)used);
+        __syncthreads();
+        for (u32 j = threadIdx.x; j < used; j += 256) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
     }
     const u64 wsum = bfq_readlane64(bfq_wave_incscan64(written), 63);
     if (lane == 0 && wsum) atomicAdd((unsigned long long *)&a.tail[3], (unsigned long long)wsum);
@@ -209,17 +247,17 @@ __global__ __launch_bounds__(256) void k_bfs_init(BfsArgs a, u64 N)
     }
 }
 
-u64 *bfq_symbol_scans(bfq_ctx *c, const u8 *bwt, u64 n, int term, const u32 *gcntIn);   // k_rank.hip
+u64 *bfq_symbol_scans(bfq_ctx *c, const u8 *bwt, u64 n, int term, const u32 *gcntIn, u32 *gcntOut);   // k_rank.hip
 
 // lcp[0..n): LCP array of the eBWT `bwt` (device, n rows, N of them terminators).  Workspace: n bytes of rank blocks,
 // 8 n bytes of queue (released on return).
-void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp)
+void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp, u32 *gcntOut)
 {
     if (!n) return;
     size_t mk = c->mark();
     const u64 ngroups = n / 256 + 1;
     BfsArgs a;
-    u64 *scanned = bfq_symbol_scans(c, bwt, n, term, nullptr);
+    u64 *scanned = bfq_symbol_scans(c, bwt, n, term, nullptr, gcntOut);   // the counts stay for the LF table build
     u64 *rank = c->alloc<u64>((ngroups * 4 + 2) * 8);
     KLAUNCH(c, K_RANK_BUILD, 2.0 * (double)n, k_rankblocks, bfq_grid(ngroups, 4), 256, bwt, n, (u32)(term & 0xFF), (const u64 *)scanned, ngroups, rank, c->d_cnt);
     c->fetchCounters();                                            // symbol totals -> F
@@ -247,7 +285,7 @@ void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lc
         HIP_CHECK(hipMemsetAsync(a.tail + 1 + (cur ^ 1), 0, 8, c->stream));
         // per interval: two 64-B rank blocks, per child one LCP probe + store, 8 B of queue in and out
         if (qend > qbeg)
-            KLAUNCH(c, K_BFS, 160.0 * (double)(qend - qbeg), k_bfs_level<false>, bfq_grid(qend - qbeg, 256), 256, a, qbeg, qend, level, cur);
+            KLAUNCH(c, K_BFS, 160.0 * (double)(qend - qbeg), k_bfs_level<false>, bfq_grid(qend - qbeg, 256 * 8), 256, a, qbeg, qend, level, cur);
         if (nside) KLAUNCH(c, K_BFS, 0.0, k_bfs_level<true>, bfq_grid(nside, 256), 256, a, 0ull, 0ull, level, cur);
         HIP_CHECK(hipMemcpyAsync(t, a.tail, 40, hipMemcpyDeviceToHost, c->stream));
         c->sync();

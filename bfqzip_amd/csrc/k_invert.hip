@@ -86,6 +86,15 @@ __global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *_
     }
 }
 
+__global__ __launch_bounds__(256) void k_fixed_offsets(u64 N, u64 L, u64 *__restrict__ roff)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i <= N; i += (u64)gridDim.x * blockDim.x) roff[i] = i * L;
+}
+void bfq_fixed_offsets(bfq_ctx *c, u64 N, u64 L, u64 *d_roff)
+{
+    KLAUNCH(c, K_MISC, 8.0 * (double)N, k_fixed_offsets, bfq_grid(N + 1, 256), 256, N, L, d_roff);
+}
+
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens)
 {
     if (!N) return;

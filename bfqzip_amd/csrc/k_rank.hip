@@ -102,12 +102,12 @@ __global__ __launch_bounds__(256) void k_lf_build(const u8 *__restrict__ bwt, co
 }
 
 // occurrences of every symbol before each 256-row group ([6][ngroups], arena) + the totals in d_cnt->tot
-u64 *bfq_symbol_scans(bfq_ctx *c, const u8 *bwt, u64 n, int term, const u32 *gcntIn)
+u64 *bfq_symbol_scans(bfq_ctx *c, const u8 *bwt, u64 n, int term, const u32 *gcntIn, u32 *gcntOut)
 {
     u64 ngroups = n / 256 + 1;
     u64 *scanned = c->alloc<u64>(6 * ngroups);
     size_t m = c->mark();
-    u32 *gcnt = gcntIn ? const_cast<u32 *>(gcntIn) : c->alloc<u32>(6 * ngroups);
+    u32 *gcnt = gcntIn ? const_cast<u32 *>(gcntIn) : gcntOut ? gcntOut : c->alloc<u32>(6 * ngroups);
     if (!gcntIn) KLAUNCH(c, K_RANK_BUILD, (double)n, k_lf_count, bfq_grid(ngroups, 4), 256, bwt, n, (u32)(term & 0xFF), gcnt, ngroups, c->d_cnt);
     for (int s = 0; s < 6; s++) bfq_exscan_u32(c, gcnt + (u64)s * ngroups, scanned + (u64)s * ngroups, ngroups, &c->d_cnt->tot[s]);
     c->release(m);
@@ -120,7 +120,7 @@ RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int ter
     u64 ngroups = n / 256 + 1;
     u64 *lfq = c->alloc<u64>(n + 8);
     size_t m = c->mark();
-    u64 *scanned = bfq_symbol_scans(c, bwt, n, term, gcntIn);
+    u64 *scanned = bfq_symbol_scans(c, bwt, n, term, gcntIn, nullptr);
     KLAUNCH(c, K_RANK_FINAL, 10.0 * (double)n, k_lf_build, bfq_grid(ngroups, 4), 256, bwt, qs, n, (u32)(term & 0xFF),
             (const u64 *)scanned, ngroups, (const DevCounters *)c->d_cnt, lfq);
     c->release(m);

@@ -30,6 +30,7 @@ extern "C" {
 #define BFQ_E_TOO_LONG     -5   /* read longer than BFQ_MAX_READ_LEN                       */
 #define BFQ_E_FREQ3        -6   /* three frequent symbols: assert of bfq_int.cpp:505        */
 #define BFQ_E_NOMEM        -7
+#define BFQ_E_IO           -8   /* file read / write failed (the *_fd entry points)          */
 
 #define BFQ_MAX_READ_LEN 65000  /* LCP is held in 16 bits (reference: LONGEST 10000, bfq_int.cpp:30) */
 
@@ -127,6 +128,16 @@ int bfq_smooth_invert_fastq(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t *h_b
                             const void *h_lcp, int lcp_bytes, uint64_t n,
                             const uint8_t *h_headers, uint64_t headers_len,
                             uint8_t *h_out, uint64_t cap, uint64_t *out_len, bfq_stats *st);
+
+/* ---- the two tools on open files (what the drop-in executables call): same operations as bfq_fastq_build_ebwt
+ * and bfq_smooth_invert_fastq, the bytes moved between the files and the GPU by the library's pinned staging
+ * pipeline (pread / pwrite by several threads: no mapping, no intermediate copy of a whole file in host memory).
+ * Outputs are written from offset 0 of descriptors the caller opened for writing (and truncated); a descriptor
+ * < 0 = not wanted / not given.  lcp_bytes: 1, 2 or 4 (eGap --lbytes; 1 saturates at 255). */
+int bfq_fastq_build_ebwt_fd(bfq_ctx *c, int fastq_fd, uint64_t len, int term_out, int bwt_fd, int bwtqs_fd,
+                            int lcp_fd, int lcp_bytes, uint64_t *n_rows, uint64_t *n_reads);
+int bfq_smooth_invert_fastq_fd(bfq_ctx *c, int bwt_fd, int bwtqs_fd, int lcp_fd, int lcp_bytes, uint64_t n,
+                               int headers_fd, uint64_t headers_len, int out_fd, uint64_t *out_len, bfq_stats *st);
 
 /* ---- one block of BFQzip_parallel.py as one call (BFQzip_parallel.py:277-285 runs `BFQzip.py <block> --rebuild -0
  * [--headers]` per block; :325-360 appends mate block k of file 2 to block k of file 1; :153-172 cuts the

@@ -94,7 +94,10 @@ def test_edge_cases(engine, orc):
     one = (A(b"ACGTN"), A(b"IIII#"), np.array([0, 5], np.uint64))
     single_base = (A(b"A"), A(b"I"), np.array([0, 1], np.uint64))
     with_empty = (A(b"ACGTAC"), A(b"IIIIII"), np.array([0, 3, 3, 6], np.uint64))     # an empty read in the middle
-    for b, q, r in (one, single_base, with_empty):
+    # lengths 1 and 3: n - N is a multiple of N although the reads differ in length (the equal-length guess of
+    # bfq_smooth_invert must notice and fall back to counting)
+    uneven = (A(b"AACG"), A(b"IIII"), np.array([0, 1, 4], np.uint64))
+    for b, q, r in (one, single_base, with_empty, uneven):
         _check_against_oracle(engine, orc, b, q, r, m=2, k=1)
     # many identical reads: segments far larger than a wavefront (k_refine_big), ties by read index
     rd = A(b"ACGTTGCAACGTACGTTTGACCAGTACGATCGATCGTAGCTAGCTAGCATCGATCAGCTACGATCGATCAGCATCGA")
