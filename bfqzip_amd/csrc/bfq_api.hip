@@ -6,6 +6,7 @@
 //   step 4  LF inversion -> reads
 // Everything runs on the context's stream inside one device workspace.
 #include <math.h>
+#include <time.h>
 #include <stdlib.h>
 #include <stdio.h>
 #include <string.h>
@@ -28,7 +29,11 @@ void bfq_ctx::reserve(size_t bytes)
     bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
     if (bytes > wsCap) {
         if (ws) { HIP_CHECK(hipStreamSynchronize(stream)); HIP_CHECK(hipFree(ws)); ws = nullptr; wsCap = 0; }
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         hipError_t e = hipMalloc((void **)&ws, bytes);
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (getenv("BFQ_TRACE")) fprintf(stderr, "[bfq] workspace %.1f GiB: hipMalloc %.3f s\n", bytes / 1073741824.0, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
         if (e != hipSuccess) {
             ws = nullptr;
             char b[160];
@@ -165,6 +170,7 @@ extern "C" void bfq_destroy(bfq_ctx *c)
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->d_powtab) (void)hipFree(c->d_powtab);
     if (c->d_qthr) (void)hipFree(c->d_qthr);
+    if (c->copyStream) (void)hipStreamDestroy(c->copyStream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -309,7 +315,41 @@ static void count_lengths(bfq_ctx *c, const RankIndex &R, u64 *d_roff, u32 *lens
     check_counters(c);
     if (tot2 != n - N) throw BfqError{BFQ_E_NOT_EBWT, "LF walks do not cover the eBWT"};
 }
-static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals, u32 *lens = nullptr)
+// so != nullptr: the outputs are the line streams OUT.fq.dna / OUT.fq.qs (d_out_bases / d_out_quals hold total + N bytes);
+// with pinned host destinations the inversion runs in read-range chunks and every finished chunk is copied to the host on
+// a second stream while the next one is walked.
+struct StreamOut { u8 *h_dna, *h_qs; };
+static void invert_lines(bfq_ctx *c, const RankIndex &R, const u64 *d_roff, u8 *d_dna, u8 *d_qs, const StreamOut *so)
+{
+    const u64 N = c->N;
+    const bool pinned = (!so->h_dna || bfq_is_pinned(so->h_dna)) && (!so->h_qs || bfq_is_pinned(so->h_qs));
+    const int C = (pinned && N >= (1u << 16) && !getenv("BFQ_NO_OVERLAP")) ? 8 : 1;
+    if (C == 1) {
+        bfq_invert(c, R, N, d_roff, c->P.B, d_dna, d_qs, 0, ~0ull, true);
+        const u64 sl = (c->n - N) + N;
+        if (so->h_dna) bfq_download(c, so->h_dna, d_dna, sl);
+        if (so->h_qs) bfq_download(c, so->h_qs, d_qs, sl);
+        return;
+    }
+    if (!c->copyStream) HIP_CHECK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+    u64 first[9], off[9];
+    for (int j = 0; j <= C; j++) first[j] = N * (u64)j / C;
+    for (int j = 0; j <= C; j++) HIP_CHECK(hipMemcpyAsync(&off[j], d_roff + first[j], 8, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    hipEvent_t ev[8];
+    for (int j = 0; j < C; j++) {
+        HIP_CHECK(hipEventCreateWithFlags(&ev[j], hipEventDisableTiming));
+        bfq_invert(c, R, N, d_roff, c->P.B, d_dna, d_qs, first[j], first[j + 1] - first[j], true);
+        HIP_CHECK(hipEventRecord(ev[j], c->stream));
+        HIP_CHECK(hipStreamWaitEvent(c->copyStream, ev[j], 0));
+        const u64 b0 = off[j] + first[j], b1 = off[j + 1] + first[j + 1];
+        if (so->h_dna) HIP_CHECK(hipMemcpyAsync(so->h_dna + b0, d_dna + b0, b1 - b0, hipMemcpyDeviceToHost, c->copyStream));
+        if (so->h_qs) HIP_CHECK(hipMemcpyAsync(so->h_qs + b0, d_qs + b0, b1 - b0, hipMemcpyDeviceToHost, c->copyStream));
+    }
+    HIP_CHECK(hipStreamSynchronize(c->copyStream));
+    for (int j = 0; j < C; j++) (void)hipEventDestroy(ev[j]);
+}
+static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals, u32 *lens = nullptr, const StreamOut *so = nullptr)
 {
     u64 n = c->n, N = c->N;
     if (!n) return;
@@ -324,6 +364,7 @@ static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_
     u8 *in = c->alloc<u8>(n + 64);
     bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
     bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n);
+    if (so) { invert_lines(c, R, d_roff, d_out_bases, d_out_quals, so); return; }
     bfq_invert(c, R, N, d_roff, c->P.B, d_out_bases, d_out_quals);
     if (guessed) {
         c->fetchCounters();
@@ -453,7 +494,7 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
         u8 *in_bwt = c->textBuf(2 * npad + 256), *in_qs = in_bwt + npad;
         bfq_upload(c, in_bwt, h_bwt, n);
         c->zeroCounters();
-        if (n) KLAUNCH(c, K_MISC, (double)n, k_count_byte, bfq_grid(n / 16 + 1, 256), 256, (const u8 *)in_bwt, n, (u32)(c->P.term & 0xFF), &c->d_cnt->pad[0]);
+        if (n) KLAUNCH(c, K_MISC, (double)n, k_count_byte, (unsigned)(n / 4096 + 1 < 2048 ? n / 4096 + 1 : 2048), 256, (const u8 *)in_bwt, n, (u32)(c->P.term & 0xFF), &c->d_cnt->pad[0]);
         c->fetchCounters();
         const u64 N = c->h_cnt.pad[0];
         if (n && N == 0) throw BfqError{BFQ_E_NOT_EBWT, "no terminator in the eBWT"};
@@ -641,42 +682,45 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         DevFastq fq;
         bfq_fastq_parse(c, d_fq, len, &fq);
         J->n_reads = fq.N; J->total_bases = fq.total;
-        u8 *ob = c->alloc<u8>(fq.total + 64), *oq = c->alloc<u8>(fq.total + 64);
+        const bool wantStreams = J->out_dna || J->out_qs || J->out_hdr;
+        const bool lines = J->out_dna || J->out_qs;               // the inversion writes the line streams itself
+        const u64 sl = fq.total + fq.N;
+        if (lines && sl > J->cap_stream) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
+        u8 *ob = c->alloc<u8>((lines ? sl : fq.total) + 64), *oq = c->alloc<u8>((lines ? sl : fq.total) + 64);
         // per part: index of its first record, and where its share of every output starts (np + 1 entries each)
         u64 *d_pidx = c->alloc<u64>(np + 1), *d_pick = c->alloc<u64>(4 * (np + 1));
         bfq_fastq_part_index(c, &fq, ps.data(), np, d_pidx);
-        size_t m = c->mark();
-        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
-        steps234_device(c, fq.roff, ob, oq);
-        c->release(m);                                         // the formatted text may reuse the pipeline's space:
-        c->d_bwt = c->d_qual = nullptr; c->d_lcp = nullptr; c->d_gcnt = nullptr;   // the eBWT is gone (bfq_fetch_ebwt refuses)
         std::vector<u64> hp(4 * (np + 1), 0);
         bool pickF = false, pickS = false, pickH = false;
         HIP_CHECK(hipMemcpyAsync(hp.data(), d_pidx, 8 * (np + 1), hipMemcpyDeviceToHost, c->stream));
+        if (J->out_hdr) {                                      // the header stream needs only the parsed text: out before the sort starts
+            u8 *d_hdr = nullptr;
+            u64 *hOff = nullptr;
+            u64 hl = 0;
+            bfq_fastq_hdr_stream(c, fq.N, d_fq, &fq, &d_hdr, &hl, &hOff);
+            J->hdr_len = hl;
+            if (hl > J->cap_hdr) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
+            bfq_download(c, J->out_hdr, d_hdr, hl);
+            bfq_pick_u64(c, hOff, d_pidx, np + 1, 0, d_pick + 3 * (np + 1));
+            pickH = true;
+        }
+        if (wantStreams) { bfq_pick_u64(c, fq.roff, d_pidx, np + 1, 1, d_pick + 2 * (np + 1)); pickS = true; }   // roff[i] + i
+        size_t m = c->mark();
+        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
+        StreamOut so{J->out_dna, J->out_qs};
+        steps234_device(c, fq.roff, ob, oq, nullptr, lines ? &so : nullptr);
+        if (lines) J->stream_len = sl;
+        c->release(m);                                         // the formatted text may reuse the pipeline's space:
+        c->d_bwt = c->d_qual = nullptr; c->d_lcp = nullptr; c->d_gcnt = nullptr;   // the eBWT is gone (bfq_fetch_ebwt refuses)
         if (J->out_fastq) {
             u8 *d_out = nullptr;
             u64 *recOff = nullptr;
-            u64 ol = bfq_fastq_format(c, ob, oq, fq.roff, fq.N, J->keep_headers ? 2 : 0, d_fq, len, &fq, &d_out, &recOff);
+            u64 ol = bfq_fastq_format(c, ob, oq, fq.roff, fq.N, J->keep_headers ? 2 : 0, d_fq, len, &fq, &d_out, &recOff, lines);
             J->fastq_len = ol;
             if (ol > J->cap_fastq) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
             bfq_download(c, J->out_fastq, d_out, ol);
             bfq_pick_u64(c, recOff, d_pidx, np + 1, 0, d_pick + (np + 1));
             pickF = true;
-        }
-        if (J->out_dna || J->out_qs || J->out_hdr) {
-            u8 *d_dna = nullptr, *d_qs = nullptr, *d_hdr = nullptr;
-            u64 *hOff = nullptr;
-            u64 hl = 0, sl = fq.total + fq.N;
-            bfq_fastq_streams(c, ob, oq, fq.roff, fq.N, fq.total, d_fq, &fq, &d_dna, &d_qs, J->out_hdr ? &d_hdr : nullptr, &hl, &hOff);
-            J->stream_len = sl; J->hdr_len = hl;
-            if (((J->out_dna || J->out_qs) && sl > J->cap_stream) || (J->out_hdr && hl > J->cap_hdr))
-                throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
-            if (J->out_dna) bfq_download(c, J->out_dna, d_dna, sl);
-            if (J->out_qs) bfq_download(c, J->out_qs, d_qs, sl);
-            if (J->out_hdr) bfq_download(c, J->out_hdr, d_hdr, hl);
-            bfq_pick_u64(c, fq.roff, d_pidx, np + 1, 1, d_pick + 2 * (np + 1));           // roff[i] + i
-            pickS = true;
-            if (J->out_hdr) { bfq_pick_u64(c, hOff, d_pidx, np + 1, 0, d_pick + 3 * (np + 1)); pickH = true; }
         }
         HIP_CHECK(hipMemcpyAsync(hp.data() + (np + 1), d_pick + (np + 1), 8 * 3 * (np + 1), hipMemcpyDeviceToHost, c->stream));
         c->fetchCounters();

@@ -60,6 +60,7 @@ struct RankIndex {
 struct bfq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t copyStream = nullptr;   // device -> host copies that overlap the tail of the inversion
     bfq_params P;
     std::string err;
 
@@ -179,7 +180,10 @@ void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual,
 // LF walks: lengths only, then emission at given offsets
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);
 void bfq_fixed_offsets(bfq_ctx *c, u64 N, u64 L, u64 *d_roff);   // d_roff[i] = i * L, i <= N
-void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals);
+// reads [first, first + count) (count ~0: all from first); lines: outputs are line streams (read i at roff[i] + i, then '\n')
+void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals, u64 first = 0,
+                u64 count = ~0ull, bool lines = false);
+bool bfq_is_pinned(const void *p);
 
 void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, u64 *d_roff);
 
@@ -187,6 +191,5 @@ void bfq_synth_launch(bfq_ctx *c, const bfq_synth *s, u8 *d_bases, u8 *d_quals, 
 struct DevFastq { u64 N, total; void *rec; u64 *roff; u8 *bases, *quals; u64 *lineEnd; };
 void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq);
 u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, int mode, const u8 *d_hdr,
-                     u64 hdrLen, const DevFastq *fq, u8 **d_out, u64 **recOffOut = nullptr);
-void bfq_fastq_streams(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, const u8 *d_fastq,
-                       const DevFastq *fq, u8 **d_dna, u8 **d_qs, u8 **d_hdr, u64 *hdrLen, u64 **hOffOut = nullptr);
+                     u64 hdrLen, const DevFastq *fq, u8 **d_out, u64 **recOffOut = nullptr, bool lines = false);
+void bfq_fastq_hdr_stream(bfq_ctx *c, u64 N, const u8 *d_fastq, const DevFastq *fq, u8 **d_hdr, u64 *hdrLen, u64 **hOffOut = nullptr);

@@ -16,6 +16,8 @@
 #include <stdlib.h>
 #include <unistd.h>
 #include <errno.h>
+#include <time.h>
+#include <stdio.h>
 #include <thread>
 #include <algorithm>
 #include <atomic>
@@ -26,13 +28,13 @@ static int io_threads()
     static const int t = [] {
         if (const char *e = getenv("BFQ_IO_THREADS")) { int v = atoi(e); if (v >= 1 && v <= BFQ_IO_MAX_WORKERS) return v; }
         unsigned hw = std::thread::hardware_concurrency();
-        int v = hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
+        int v = hw >= 32 ? 8 : hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
         return v;
     }();
     return t;
 }
 
-static bool is_pinned(const void *p)
+bool bfq_is_pinned(const void *p)
 {
     hipPointerAttribute_t a;
     memset(&a, 0, sizeof a);
@@ -104,8 +106,12 @@ static bool host_put(const HostRef &h, size_t off, const char *src, size_t sz)
 }
 
 // Chunk i of the transfer belongs to worker i mod T.  `up`: host -> device, else device -> host.
+static bool io_trace() { static const bool t = getenv("BFQ_TRACE") != nullptr; return t; }
+static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+
 static void staged_copy(bfq_ctx *c, char *dev, HostRef host, size_t len, bool up)
 {
+    const double t0 = io_trace() ? now_s() : 0;
     c->ioInit();
     const int T = c->ioWorkers;
     const size_t CH = BFQ_IO_STAGE_BYTES;
@@ -155,6 +161,11 @@ static void staged_copy(bfq_ctx *c, char *dev, HostRef host, size_t len, bool up
     for (int t = 0; t < T; t++)
         if (errs[t] != hipSuccess) throw BfqError{BFQ_E_HIP, std::string("staged transfer: ") + hipGetErrorString(errs[t])};
     if (ioFail) throw BfqError{BFQ_E_IO, std::string("staged transfer: file read / write failed: ") + strerror(errno)};
+    if (io_trace()) {
+        const double dt = now_s() - t0;
+        fprintf(stderr, "[bfq io] %s %s %.2f GB in %.3f s = %.1f GB/s (%d workers)\n", up ? "upload" : "download", host.ptr ? "memory" : "file",
+                len / 1e9, dt, len / 1e9 / dt, T);
+    }
 }
 
 // host -> device.  Ordered after everything already on the context's stream; when it returns the
@@ -162,7 +173,7 @@ static void staged_copy(bfq_ctx *c, char *dev, HostRef host, size_t len, bool up
 void bfq_upload(bfq_ctx *c, void *d_dst, HostRef src, size_t len)
 {
     if (!len) return;
-    if (src.ptr && (is_pinned(src.ptr) || len < (1u << 20))) {
+    if (src.ptr && (bfq_is_pinned(src.ptr) || len < (1u << 20))) {
         HIP_CHECK(hipMemcpyAsync(d_dst, src.ptr, len, hipMemcpyHostToDevice, c->stream));
         return;
     }
@@ -175,7 +186,7 @@ void bfq_upload(bfq_ctx *c, void *d_dst, const void *h_src, size_t len) { bfq_up
 void bfq_download(bfq_ctx *c, HostRef dst, const void *d_src, size_t len)
 {
     if (!len) return;
-    if (dst.ptr && (is_pinned(dst.ptr) || len < (1u << 20))) {
+    if (dst.ptr && (bfq_is_pinned(dst.ptr) || len < (1u << 20))) {
         HIP_CHECK(hipMemcpyAsync(dst.ptr, d_src, len, hipMemcpyDeviceToHost, c->stream));
         return;
     }

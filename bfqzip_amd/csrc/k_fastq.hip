@@ -9,8 +9,8 @@
 //                             (CR before LF stripped; len(DNA) != len(QS) is an error, checkFASTQ.py:18-32)
 //   k_fq_gather             : lines 2 and 4 -> bases / quals back to back (one wave per read)
 //   k_fq_format             : header line (verbatim, or "@"), bases, "+", quals (one wave per read)
-//   k_fq_lines / k_fq_hdr_gather : the separate streams of BFQzip.py --m2/--m3 (OUT.fq.dna, OUT.fq.qs, OUT.h):
-//                             every read's bases / qualities / header as one line each
+//   k_fq_hdr_gather         : the header stream of BFQzip.py --m3 (OUT.h): every read's header as one line
+//                             (OUT.fq.dna / OUT.fq.qs are written by the inversion kernel itself)
 #include "bfq_internal.h"
 #include "bfq_device.h"
 
@@ -125,12 +125,13 @@ __global__ __launch_bounds__(256) void k_fq_recsize(const u64 *__restrict__ roff
 __global__ __launch_bounds__(256) void k_fq_format(const u8 *__restrict__ bases, const u8 *__restrict__ quals,
                                                    const u64 *__restrict__ roff, const u8 *__restrict__ hdr,
                                                    const u64 *__restrict__ hStart, const u32 *__restrict__ hLen,
-                                                   const u64 *__restrict__ recOff, u64 N, u8 *__restrict__ out)
+                                                   const u64 *__restrict__ recOff, u64 N, u8 *__restrict__ out, int lines)
 {
     u32 lane = bfq_lane();
     u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
         u64 b = roff[i], L = roff[i + 1] - b, o = recOff[i];
+        if (lines) b += i;                                       // bases / quals given as line streams (read i at roff[i] + i)
         u64 hs = hdr ? hStart[i] : 0, hl = hdr ? hLen[i] : 1;
         for (u64 k = lane; k < hl; k += 64) out[o + k] = hdr ? hdr[hs + k] : (u8)'@';
         o += hl;
@@ -142,18 +143,6 @@ __global__ __launch_bounds__(256) void k_fq_format(const u8 *__restrict__ bases,
     }
 }
 
-// dna[roff[i] + i ..] = bases of read i + '\n'; same for the qualities (what `sed -n 2~4p` / `4~4p` cut from OUT.fq)
-__global__ __launch_bounds__(256) void k_fq_lines(const u8 *__restrict__ bases, const u8 *__restrict__ quals,
-                                                  const u64 *__restrict__ roff, u64 N, u8 *__restrict__ dna, u8 *__restrict__ qs)
-{
-    u32 lane = bfq_lane();
-    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
-        u64 b = roff[i], L = roff[i + 1] - b, o = b + i;
-        for (u64 k = lane; k < L; k += 64) { dna[o + k] = bases[b + k]; qs[o + k] = quals[b + k]; }
-        if (lane == 0) { dna[o + L] = 10; qs[o + L] = 10; }
-    }
-}
 __global__ __launch_bounds__(256) void k_fq_hdrsize(const FqRec *__restrict__ rec, u64 N, u32 *__restrict__ sizes)
 {
     for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) sizes[i] = rec[i].hdrLen + 1;
@@ -244,7 +233,7 @@ void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq)
 // Headers: mode 0 = "@"; 1 = d_hdr is a text of header lines (bfq_int -H); 2 = d_hdr is the FASTQ
 // text parsed into `fq` (its records' own header lines).  Returns the formatted length, text in *d_out (arena).
 u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, int mode, const u8 *d_hdr,
-                     u64 hdrLen, const DevFastq *fq, u8 **d_out, u64 **recOffOut)
+                     u64 hdrLen, const DevFastq *fq, u8 **d_out, u64 **recOffOut, bool lines)
 {
     u64 *hStart = nullptr;
     u32 *hLen = nullptr;
@@ -271,23 +260,19 @@ u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     if (N) {
         u64 waves = N < (1u << 18) ? N : (1u << 18);
         KLAUNCH(c, K_FASTQ, 2.0 * (double)outLen, k_fq_format, ceil_div(waves, 4), 256, d_bases, d_quals, d_roff,
-                mode ? d_hdr : (const u8 *)nullptr, (const u64 *)hStart, (const u32 *)hLen, (const u64 *)recOff, N, out);
+                mode ? d_hdr : (const u8 *)nullptr, (const u64 *)hStart, (const u32 *)hLen, (const u64 *)recOff, N, out, lines ? 1 : 0);
     }
     *d_out = out;
     if (recOffOut) *recOffOut = recOff;
     return outLen;
 }
 
-// The streams of BFQzip.py --m2/--m3: *d_dna / *d_qs hold total + N bytes each; *d_hdr (when asked for) the
-// header lines of the parsed FASTQ `fq`, *hdrLen bytes.
-void bfq_fastq_streams(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, const u8 *d_fastq,
-                       const DevFastq *fq, u8 **d_dna, u8 **d_qs, u8 **d_hdr, u64 *hdrLen, u64 **hOffOut)
+// The header stream of BFQzip.py --m3 (OUT.h = `sed -n 1~4p in.fastq`): the header lines of the parsed FASTQ `fq`, one
+// per line; *hdrLen bytes in *d_hdr, line offsets in *hOffOut.  (The OUT.fq.dna / OUT.fq.qs streams are written by the
+// inversion itself, k_invert<.., 1>.)
+void bfq_fastq_hdr_stream(bfq_ctx *c, u64 N, const u8 *d_fastq, const DevFastq *fq, u8 **d_hdr, u64 *hdrLen, u64 **hOffOut)
 {
-    u8 *dna = c->alloc<u8>(total + N + 64), *qs = c->alloc<u8>(total + N + 64);
     u64 waves = N < (1u << 18) ? N : (1u << 18);
-    if (N) KLAUNCH(c, K_FASTQ, 4.0 * (double)total + 2.0 * (double)N, k_fq_lines, ceil_div(waves, 4), 256, d_bases, d_quals, d_roff, N, dna, qs);
-    *d_dna = dna; *d_qs = qs;
-    if (!d_hdr) return;
     u32 *sizes = c->alloc<u32>(N + 1);
     u64 *hOff = c->alloc<u64>(N + 2);
     if (N) KLAUNCH(c, K_FASTQ, 28.0 * (double)N, k_fq_hdrsize, bfq_grid(N, 256), 256, (const FqRec *)fq->rec, N, sizes);

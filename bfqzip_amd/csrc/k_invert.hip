@@ -39,12 +39,16 @@ __device__ __forceinline__ void store_tail(u8 *dst, u64 v, u32 cnt)
 // The walk produces a read back to front.  Output bytes are collected in chunks of 16 counted from the
 // read's END ([end-16, end), [end-32, end-16), ...), each stored as two unaligned 8-byte words, so only the
 // front of the read (len mod 16 bytes) needs narrower stores.
-template <int NT>
-__global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 N, const u64 *__restrict__ roff, int B,
+// NL: the outputs are the line streams of BFQzip.py --m2/--m3 (OUT.fq.dna / OUT.fq.qs: read i at roff[i] + i, followed
+// by a newline) instead of the reads back to back.  Reads [first, first + count).
+template <int NT, int NL>
+__global__ __launch_bounds__(256) void k_invert(RankIndex R, u64 first, u64 count, const u64 *__restrict__ roff, int B,
                                                 u8 *__restrict__ out_bases, u8 *__restrict__ out_quals, DevCounters *cnt)
 {
-    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (u64)gridDim.x * blockDim.x) {
-        const u64 lo = roff[i], end = roff[i + 1];
+    for (u64 t = (u64)blockIdx.x * blockDim.x + threadIdx.x; t < count; t += (u64)gridDim.x * blockDim.x) {
+        const u64 i = first + t;
+        const u64 lo = roff[i] + (NL ? i : 0), end = roff[i + 1] + (NL ? i : 0);
+        if (NL) { out_bases[end] = 10; out_quals[end] = 10; }
         u64 pos = end, j = i;
         u64 bl = 0, bh = 0, ql = 0, qh = 0;                            // 16 output bytes of each stream
         u32 have = 0;                                                  // bytes in the current chunk (filled from the top)
@@ -101,14 +105,15 @@ void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens)
     KLAUNCH(c, K_INVERT_COUNT, 64.0 * (double)(R.n - N), k_invert_count, bfq_grid(N, 256), 256, R, N, lens, c->d_cnt);
 }
 
-void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals)
+void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B, u8 *out_bases, u8 *out_quals, u64 first, u64 count,
+                bool lines)
 {
-    if (!N) return;
+    if (count == ~0ull) count = N - first;
+    if (!count) return;
     static const int nt = getenv("BFQ_INVERT_NT") ? atoi(getenv("BFQ_INVERT_NT")) : 1;   // nt loads: -15% (L1 bypass)
-    if (nt)
-        KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert<1>, bfq_grid(N, 256), 256, R, N, d_roff, B, out_bases, out_quals,
-                c->d_cnt);
-    else
-        KLAUNCH(c, K_INVERT, 68.0 * (double)(R.n - N), k_invert<0>, bfq_grid(N, 256), 256, R, N, d_roff, B, out_bases, out_quals,
-                c->d_cnt);
+    const double bytes = 68.0 * (double)(R.n - N) * ((double)count / (double)N);
+#define INV_LAUNCH(NTV, NLV) KLAUNCH(c, K_INVERT, bytes, (k_invert<NTV, NLV>), bfq_grid(count, 256), 256, R, first, count, d_roff, B, out_bases, out_quals, c->d_cnt)
+    if (nt) { if (lines) INV_LAUNCH(1, 1); else INV_LAUNCH(1, 0); }
+    else { if (lines) INV_LAUNCH(0, 1); else INV_LAUNCH(0, 0); }
+#undef INV_LAUNCH
 }

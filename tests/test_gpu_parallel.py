@@ -70,7 +70,8 @@ def test_paired_m1_streams_3M_reads_two_ranks(orc, tmp_path):
     f1, f2 = str(tmp_path / "s_1.fastq"), str(tmp_path / "s_2.fastq")
     _synth_fastq(f1, 777, N, L, "1"); _synth_fastq(f2, 778, N, L, "2")
     out = str(tmp_path / "OUT")
-    _launch(2, [f1, f2, "-p", "-o", out, "-t", str(T), "--m3", "--M", "1"], str(tmp_path), timeout=1500)
+    # --pinned: page-locked output buffers = the path that copies finished read ranges out while the inversion goes on
+    _launch(2, [f1, f2, "-p", "-o", out, "-t", str(T), "--m3", "--M", "1", "--pinned"], str(tmp_path), timeout=1500)
     names = parallel.output_names([f1, f2], out, True)
     check_streams(names, [f1, f2])                                                  # all blocks: streams == sed of the FASTQ
     ins = [np.fromfile(f, np.uint8) for f in (f1, f2)]
