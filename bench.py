@@ -203,6 +203,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-dropin", action="store_true")
+    ap.add_argument("--piles", type=int, default=0, help="bfq_params.piles: 1 = step 1 pile by pile (13 n bytes of workspace instead of 28.6 n)")
     ap.add_argument("--M", type=int, default=2)
     ap.add_argument("--B", type=int, default=None)
     args = ap.parse_args()
@@ -229,7 +230,7 @@ def main():
     tstart = time.perf_counter()
     Nw, L = parse_workload(args.workload)
     B = args.B if args.B is not None else (1 if (Nw, L) == (30_000_000, 150) else 0)   # BASELINE.json configs[2]: B=1
-    par = dict(k=16, m=5, v=ord(">"), f=40, t=20, M=args.M, B=B)                      # -m 5: what BFQzip.py passes
+    par = dict(k=16, m=5, v=ord(">"), f=40, t=20, M=args.M, B=B, piles=args.piles)    # -m 5: what BFQzip.py passes
     eng = api.Engine(local, **par)
 
     def log(msg):

@@ -25,8 +25,8 @@ SYMBOLS = [
 
 
 class Params(C.Structure):
-    _fields_ = [(k, C.c_int32) for k in ("K", "m", "v", "f", "t", "term", "M", "B", "ext")] + \
-               [("reserved", C.c_int32 * 7)]
+    _fields_ = [(k, C.c_int32) for k in ("K", "m", "v", "f", "t", "term", "M", "B", "ext", "piles")] + \
+               [("reserved", C.c_int32 * 6)]
 
 
 class Stats(C.Structure):

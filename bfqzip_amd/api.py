@@ -25,9 +25,9 @@ class BfqError(RuntimeError):
         self.code = code
 
 
-def make_params(k=16, m=2, v=ord(">"), f=40, t=20, s=ord("#"), M=2, B=0, ext=0):
+def make_params(k=16, m=2, v=ord(">"), f=40, t=20, s=ord("#"), M=2, B=0, ext=0, piles=0):
     p = _lib.Params()
-    p.K, p.m, p.v, p.f, p.t, p.term, p.M, p.B, p.ext = k, m, v, f, t, s, M, B, ext
+    p.K, p.m, p.v, p.f, p.t, p.term, p.M, p.B, p.ext, p.piles = k, m, v, f, t, s, M, B, ext, piles
     return p
 
 

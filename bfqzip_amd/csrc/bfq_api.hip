@@ -100,7 +100,7 @@ static int host_q(double x) { return (int)round(-10 * log10(x)); }
 extern "C" void bfq_default_params(bfq_params *p)
 {
     memset(p, 0, sizeof(*p));
-    p->K = 16; p->m = 2; p->v = '>'; p->f = 40; p->t = 20; p->term = '#'; p->M = 2; p->B = 0; p->ext = 0;
+    p->K = 16; p->m = 2; p->v = '>'; p->f = 40; p->t = 20; p->term = '#'; p->M = 2; p->B = 0; p->ext = 0; p->piles = 0;
 }
 extern "C" const char *bfq_create_error(void) { return g_createErr.c_str(); }
 extern "C" const char *bfq_version(void) { return "bfqzip_amd 0.1 (gfx950)"; }
@@ -239,7 +239,7 @@ static void fill_stats(bfq_ctx *c, bfq_stats *st)
     st->num_clust_mod = s[3]; st->num_clust_alleq = s[4]; st->bases_inside = s[5];
     st->qs_smoothed = s[6]; st->modified = s[7];
     st->n_rows = c->n; st->n_reads = c->N;
-    st->n_segments = c->h_cnt.nSegs; st->n_big_segments = c->h_cnt.bigCount;
+    st->n_segments = c->h_cnt.nSegs; st->n_big_segments = c->h_cnt.bigTotal + c->h_cnt.bigCount;
 }
 
 // workspace bound for a collection of n rows (see DESIGN.md "HBM layout")
@@ -268,10 +268,27 @@ static size_t ws_need_given(u64 n, u64 N, u64 extra)
     return need;
 }
 
+// Workspace for a call that runs step 1 on n rows: in one piece (ws_need) or pile by pile (bfq_params.piles: 1 always,
+// 0 = when the one-piece workspace cannot be had, -1 never; the environment variable BFQ_PILES=0/1 overrides).
+static void reserve_step1(bfq_ctx *c, u64 n, u64 N, u64 extra)
+{
+    int mode = c->P.piles;
+    if (const char *e = getenv("BFQ_PILES")) mode = atoi(e) ? 1 : -1;
+    const u64 cap = n / 10 * 3 + (1u << 20);                     // a DNA pile holds about a quarter of the suffixes; larger ones are split again
+    c->piles = false;
+    if (mode <= 0) {
+        try { c->reserve(ws_need(n, N, extra)); return; }
+        catch (const BfqError &e) { if (mode < 0 || e.code != BFQ_E_NOMEM) throw; }
+    }
+    c->reserve(bfq_ws_need_piles(n, N, cap, extra));
+    c->piles = true;
+}
+
 // ---------------------------------------------------------------- step 1
 void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,
                       int termOut, bfq_stats *st)
 {
+    if (c->piles) { bfq_step1_piles(c, d_bases, d_quals, d_roff, N, total, termOut, st); return; }
     u64 n = total + N;
     if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^37 rows)"};
     c->n = n; c->N = N;
@@ -382,7 +399,7 @@ extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const ui
 {
     return guarded(c, [&] {
         if (st) memset(st, 0, sizeof *st);
-        c->reserve(ws_need(total + N, N, 0));
+        reserve_step1(c, total + N, N, 0);
         c->zeroCounters();
         bfq_step1_device(c, d_bases, d_quals, (const u64 *)d_read_off, N, total, c->P.term, st);
         steps234_device(c, (u64 *)d_read_off, d_out_bases, d_out_quals);
@@ -400,7 +417,7 @@ extern "C" int bfq_run_reads(bfq_ctx *c, const uint8_t *h_bases, const uint8_t *
         if (st) memset(st, 0, sizeof *st);
         if (!h_read_off) throw BfqError{BFQ_E_ARG, "null read offsets"};
         u64 total = h_read_off[N];
-        c->reserve(ws_need(total + N, N, 4 * (total + 256) + 8 * (N + 64)));
+        reserve_step1(c, total + N, N, 4 * (total + 256) + 8 * (N + 64));
         c->zeroCounters();
         u8 *db = c->alloc<u8>(total + 64), *dq = c->alloc<u8>(total + 64);
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
@@ -425,7 +442,7 @@ extern "C" int bfq_build_ebwt(bfq_ctx *c, const uint8_t *h_bases, const uint8_t 
     return guarded(c, [&] {
         if (!h_read_off) throw BfqError{BFQ_E_ARG, "null read offsets"};
         u64 total = h_read_off[N], n = total + N;
-        c->reserve(ws_need(n, N, 2 * (total + 256) + 8 * (N + 64)));
+        reserve_step1(c, n, N, 2 * (total + 256) + 8 * (N + 64));
         c->zeroCounters();
         u8 *db = c->alloc<u8>(total + 64), *dq = c->alloc<u8>(total + 64);
         u64 *dr = c->alloc<u64>(N + 1);
@@ -595,7 +612,7 @@ static u8 *fastq_upload_and_reserve(bfq_ctx *c, const TextSrc *parts, int nparts
     u64 nlines = bfq_fastq_count_lines(c, d_fq, len);
     u64 N = nlines / 4 + 1;
     u64 nb = len / 2 + 1;                                       // rows <= bytes / 2
-    c->reserve(ws_need(nb, N, 3 * (len + 4096) + 128 * (N + 64) + 8 * (nlines + 64)));
+    reserve_step1(c, nb, N, 3 * (len + 4096) + 128 * (N + 64) + 8 * (nlines + 64));
     return d_fq;
 }
 

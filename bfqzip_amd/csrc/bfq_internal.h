@@ -48,7 +48,8 @@ struct DevCounters {
     u64 hugeCount;       // segments above BFQ_HUGE_SEG rows, left to the radix rounds of k_bigseg.hip
     u64 hugeRows;        // their rows
     u64 bigClusters;     // clusters above CL_BIG rows, left to k_cluster_big
-    u64 pad[6];
+    u64 bigTotal;        // segments > 64 rows of the piles already refined (pile mode: bigCount restarts per pile)
+    u64 pad[5];
 };
 
 // the tabulated rank queries: one u64 per eBWT row (layout: bfq_rank.h)
@@ -84,6 +85,7 @@ struct bfq_ctx {
     u32 *d_gcnt = nullptr;          // symbol counts per 256-row group, written by k_emit_bwt
     int gcntTerm = -1;              // terminator byte those counts were taken with
     u64 n = 0, N = 0;
+    bool piles = false;             // step 1 runs pile by pile (k_piles.hip): set by the reservation of the current call
 
     // profiling
     bool profOn = true;
@@ -170,6 +172,9 @@ void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs, 
 // whole step 1 on device-resident reads; leaves c->d_bwt/d_qual/d_lcp
 void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,
                       int termOut, bfq_stats *st);
+// the same, one first-symbol pile at a time (k_piles.hip); workspace bound for pile records of at most `cap` rows
+void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, int termOut, bfq_stats *st);
+size_t bfq_ws_need_piles(u64 n, u64 N, u64 cap, u64 extra);
 
 // steps 2-4 pieces
 RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int term, const u32 *gcnt = nullptr);

@@ -34,7 +34,10 @@ int main(int argc, char **argv)
     // split and sorted there; the outputs are written straight from the staging buffers
     InFile buf;
     if (!buf.open(in)) { fprintf(stderr, "%s: cannot read %s\n", tool, in.c_str()); return 1; }
-    bfq_ctx *c = bfq_create(0, nullptr);
+    bfq_params P;
+    bfq_default_params(&P);
+    P.piles = 1;                                 // one process, one collection: the smaller pile-by-pile workspace is allocated faster
+    bfq_ctx *c = bfq_create(0, &P);
     if (!c) { fprintf(stderr, "%s: %s\n", tool, bfq_create_error()); return 1; }
     uint64_t n = 0, N = 0;
     OutFile bwt, qs, lcpf;

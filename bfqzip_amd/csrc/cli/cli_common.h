@@ -60,7 +60,7 @@ struct OutFile {
     int fd = -1;
     bool open(const std::string &path)
     {
-        fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        fd = ::open(path.c_str(), O_RDWR | O_CREAT | O_TRUNC, 0644);   // O_RDWR: the library maps the file to write it
         return fd >= 0;
     }
     bool close()

@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_emit_bwt(SortRec rec, u64 n, u32 termOu
         if (r0 + 4 <= n) { *(u32 *)(bwt + r0) = b4; *(u32 *)(qs + r0) = q4; }
         else for (u64 k = 0; r0 + k < n; k++) { bwt[r0 + k] = (u8)(b4 >> (8 * k)); qs[r0 + k] = (u8)(q4 >> (8 * k)); }
         p = bfq_readlane64(bfq_wave_incscan64(p), 63);         // the group's packed symbol counts
-        if (lane < 6) gcnt[(u64)lane * ngroups + g] = (u32)(p >> (10 * lane)) & 0x3FFu;
+        if (gcnt && lane < 6) gcnt[(u64)lane * ngroups + g] = (u32)(p >> (10 * lane)) & 0x3FFu;
     }
 }
 

@@ -46,7 +46,9 @@ typedef struct bfq_params {
     int32_t M;      /* 0 max, 1 mean error, 2 constant, 3 average default 2         */
     int32_t B;      /* 1 = Illumina 8-level binning               default 0         */
     int32_t ext;    /* 1 = bfq_ext arithmetic for M=3 (bfq_ext.cpp:496)             */
-    int32_t reserved[7];
+    int32_t piles;  /* step 1 pile by pile (first-symbol piles as in bfq_ext.cpp:190-348; 13 n bytes of workspace
+                       instead of 28.6 n): 1 always, 0 when the one-piece workspace cannot be had, -1 never     */
+    int32_t reserved[6];
 } bfq_params;
 
 /* Counters printed by bfq_int.cpp:1004-1019. */

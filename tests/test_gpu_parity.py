@@ -45,6 +45,7 @@ def _check_against_oracle(engine, orc, b, q, r, **par):
     full = dict(k=16, m=2, v=ord(">"), f=40, t=20, M=2, B=0)
     full.update(par)
     engine.set_params(**full)
+    full.pop("piles", None)
     p = orc.params(K=full["k"], m=full["m"], v=full["v"], f=full["f"], t=full["t"], M=full["M"], B=full["B"])
     bwt, qs, lcp = orc.build_ebwt(b, q, r)
     gb, gq, gl = engine.build_ebwt(b, q, r)
@@ -163,6 +164,33 @@ def test_bfq_ext_arithmetic(engine, orc):
     engine.set_params(m=5, M=3, ext=0)
     ib, iq, _, _ = engine.smooth_invert(bwt, qs, lcp.astype(np.uint16))
     assert not np.array_equal(iq, gq)
+
+
+def test_pile_mode(engine, orc, monkeypatch):
+    """Step 1 one first-symbol pile at a time (k_piles.hip; bfq_params.piles = 1): same eBWT / QS / LCP, same reads, same
+    statistics as the oracle -- synthetic sets in all smoothing modes, random small sets (variable length, duplicates, N,
+    empty reads), low-complexity reads (huge segments inside one pile), and the same with every pile split again by its
+    second symbol (BFQ_PILES_SPLIT: what a pile beyond the workspace goes through)."""
+    def cases():
+        for M in range(4):
+            sp = api.synth_spec(3000, 50, seed=300 + M, coverage=25)
+            yield api.synth_host(sp) + (dict(M=M, B=M & 1, m=5),)
+        rng = np.random.default_rng(77)
+        for it in range(12):
+            b, q, r = util.random_reads(rng, int(rng.integers(1, 300)), 0 if it % 4 == 0 else 1, int(rng.integers(1, 60)))
+            yield b, q, r, dict(M=int(rng.integers(0, 4)), k=int(rng.choice([1, 2, 3, 5, 16])), m=int(rng.choice([2, 3, 5])))
+        yield _low_complexity(np.random.default_rng(7)) + (dict(m=5),)
+        A = lambda s: np.frombuffer(s, np.uint8)
+        yield A(b"ACGTN"), A(b"IIII#"), np.array([0, 5], np.uint64), dict(m=2, k=1)
+        yield A(b""), A(b""), np.array([0, 0, 0], np.uint64), dict(m=2, k=1)              # only empty reads
+    for split in (False, True):
+        if split:
+            monkeypatch.setenv("BFQ_PILES_SPLIT", "1")
+        for b, q, r, par in cases():
+            st = _check_against_oracle(engine, orc, b, q, r, piles=1, **par)
+    monkeypatch.delenv("BFQ_PILES_SPLIT")
+    assert st is not None
+    engine.set_params()
 
 
 def test_bfq_int_mode_any_tie_order(engine, orc):
