@@ -24,7 +24,7 @@
 //     suffixes (or of the terminator rows) in the given eBWT -- any tool's tie order is accepted, like the
 //     reference, which sees one terminator symbol.
 // Rows whose eBWT symbol is the terminator are never extended (nothing precedes a whole read).
-// scratch/bfs_model.py is the executable model of this algorithm (checked against LCPs computed from the decoded
+// tests/bfs_model.py is the executable model of this algorithm (checked against LCPs computed from the decoded
 // suffixes, incl. eBWTs whose ties are in inconsistent order).
 //
 //   rank block (64 B, rows [64 b, 64 b + 64)): u64 count of A, C, G, N, T before the block, then the

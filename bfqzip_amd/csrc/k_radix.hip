@@ -178,11 +178,10 @@ void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes, const u
     for (int pass = 0; pass < passes; pass++) {
         const int dw = pass < 2 ? 1 : 0;
         const int shift = pass < 2 ? 16 + 8 * pass : 8 * (pass - 2);
-        const bool have = (pass == 0 && hist0);            // made by k_build_keys
-        if (have) {}
-        else if (dw)
+        const bool have = (pass == 0 && hist0);            // pass 0's counts were made by k_build_keys
+        if (!have && dw)
             KLAUNCH(c, K_RADIX_HIST, 8.0 * (double)n, k_radix_hist<u64>, nb, RS_THREADS, (const u64 *)in.w12, n, shift, hist, nb);
-        else
+        else if (!have)
             KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist<u32>, nb, RS_THREADS, (const u32 *)in.w0, n, shift, hist, nb);
         bfq_exscan_u32(c, have ? hist0 : hist, off, 256 * nb, nullptr);
         if (dw)

@@ -6,20 +6,22 @@
 // identical suffixes, already in read order (stable sort, #_i < #_j for i < j), so they
 // are final.  All other segments of >= 2 rows are refined on the following 21-symbol
 // words of the text:
-//   k_refine_chunk : one workgroup per chunk of 4096 rows.  Segment heads (and the LCP of
-//                    head rows) come straight from the sorted keys; the chunk's segments
-//                    are compacted into LDS; each wavefront takes 64 of them at a time,
-//                    packs as many as fit into its 64 lanes (one row per lane) and refines
-//                    them together, round by round, entirely in registers:
-//                      next 21-symbol word of every open row (prefetched a round ahead),
-//                      stable rank inside each sub-segment by counting over lane offsets
-//                      (DPP wave shifts), one ds_permute of the payload, new sub-segment
-//                      heads and their LCP from the words.
-//   k_refine_big   : segments longer than a wavefront: one workgroup each, ascending-only
-//                    bitonic network over the rows in global memory, full-suffix comparator.
-//                    Segments above BFQ_HUGE_SEG rows (low-complexity reads: poly-A/G tails, short
-//                    tandem repeats) are only listed here and sorted by whole-device radix rounds
-//                    (k_bigseg.hip).
+//   k_refine_chunk : one WAVEFRONT per chunk of 2048 rows, no workgroup barriers.  Segment heads (and the LCP of
+//                    head rows) come straight from the sorted keys (4 rows per lane and step, head bits OR-ed
+//                    into wave-private LDS words); the chunk's segments of >= 2 rows are compacted into LDS;
+//                    then up to 64 rows of several segments are packed one row per lane and refined together,
+//                    round by round (42 symbols each), entirely in registers:
+//                      next two 21-symbol words of every open row (fetched by word index, no division),
+//                      stable rank inside each sub-segment by one-directional compares over lane offsets
+//                      (DPP wave shifts) + ballot complement, one ds_permute of the payload and the words,
+//                      new sub-segment heads and their LCP from the words.
+//   k_refine_big   : segments of 65 .. BFQ_HUGE_SEG rows: one workgroup (or one wavefront) each, everything in
+//                    LDS -- a bitonic network over (sub-segment id, two words, original slot) that moves only a
+//                    4-byte (id, slot) word; five size classes by LDS footprint.
+//                    Segments above BFQ_HUGE_SEG rows (low-complexity reads: poly-A/G tails, short tandem
+//                    repeats) are only listed here and sorted by whole-device radix rounds (k_bigseg.hip);
+//                    k_refine_listed (a global-memory bitonic network, one workgroup per segment) is the last
+//                    resort for segments beyond even those rounds' workspace.
 // LCP convention: common prefix counted on bases only, terminators never match
 // (what bfq_int deduces from the BWT, bfq_int.cpp:139-181,183-300, and what
 // eGap --lcp hands to bfq_ext, bfq_ext.cpp:350-412).
@@ -300,7 +302,13 @@ template <int PMAX> struct BlockSortLds {
 };
 template <int NT> __device__ __forceinline__ void grp_sync()
 {
-    if (NT == 64) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+    if (NT == 64) {
+        // one wavefront: lanes exchange data through LDS across this point, so the scheduling barrier is fenced --
+        // the compiler must neither forward a lane's own LDS value nor hoist LDS accesses over it
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else __syncthreads();
 }
 template <int NT, int PMAX>
 __device__ void block_sort(const SortRec &rec, u64 s, u32 g, const u64 *__restrict__ text3, u16 *__restrict__ lcp, BlockSortLds<PMAX> &L)
