@@ -82,19 +82,33 @@ __global__ __launch_bounds__(256) void k_fq_records(const u8 *__restrict__ buf, 
     }
 }
 
+// copy len bytes with unaligned 8-byte accesses, `sub` of `nsub` lanes working together; the last word overlaps the one
+// before (no byte tail); len < 8: lane 0 alone, byte by byte
+__device__ __forceinline__ void copy_bytes(u8 *__restrict__ dst, const u8 *__restrict__ src, u64 len, u32 sub, u32 nsub)
+{
+    if (len >= 8) {
+        const u64 nw = (len + 7) >> 3;
+        for (u64 j = sub; j < nw; j += nsub) {
+            const u64 k = (8 * j + 8 <= len) ? 8 * j : len - 8;
+            *(u64 *)(dst + k) = *(const u64 *)(src + k);
+        }
+    } else if (sub == 0) {
+        for (u64 k = 0; k < len; k++) dst[k] = src[k];
+    }
+}
+
+// 16 lanes per read, 8 bytes per lane and step
 __global__ __launch_bounds__(256) void k_fq_gather(const u8 *__restrict__ buf, const FqRec *__restrict__ rec,
                                                    const u64 *__restrict__ roff, u64 N, u8 *__restrict__ bases,
                                                    u8 *__restrict__ quals)
 {
-    u32 lane = bfq_lane();
-    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
-        FqRec r = rec[i];
-        u64 o = roff[i];
-        for (u32 k = lane; k < r.len; k += 64) {
-            bases[o + k] = buf[r.seqStart + k];
-            quals[o + k] = buf[r.qualStart + k];
-        }
+    const u32 sub = threadIdx.x & 15u;
+    const u64 ngrp = ((u64)gridDim.x * blockDim.x) >> 4;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < N; i += ngrp) {
+        const FqRec r = rec[i];
+        const u64 o = roff[i];
+        copy_bytes(bases + o, buf + r.seqStart, r.len, sub, 16);
+        copy_bytes(quals + o, buf + r.qualStart, r.len, sub, 16);
     }
 }
 
@@ -127,19 +141,18 @@ __global__ __launch_bounds__(256) void k_fq_format(const u8 *__restrict__ bases,
                                                    const u64 *__restrict__ hStart, const u32 *__restrict__ hLen,
                                                    const u64 *__restrict__ recOff, u64 N, u8 *__restrict__ out, int lines)
 {
-    u32 lane = bfq_lane();
-    u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
-    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < N; i += nwaves) {
+    const u32 sub = threadIdx.x & 15u;                           // 16 lanes per record, 8 bytes per lane and step
+    const u64 ngrp = ((u64)gridDim.x * blockDim.x) >> 4;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < N; i += ngrp) {
         u64 b = roff[i], L = roff[i + 1] - b, o = recOff[i];
         if (lines) b += i;                                       // bases / quals given as line streams (read i at roff[i] + i)
-        u64 hs = hdr ? hStart[i] : 0, hl = hdr ? hLen[i] : 1;
-        for (u64 k = lane; k < hl; k += 64) out[o + k] = hdr ? hdr[hs + k] : (u8)'@';
+        const u64 hl = hdr ? hLen[i] : 1;
+        if (hdr) copy_bytes(out + o, hdr + hStart[i], hl, sub, 16);
+        else if (sub == 0) out[o] = (u8)'@';
         o += hl;
-        if (lane == 0) { out[o] = 10; out[o + 1 + L] = 10; out[o + 2 + L] = (u8)'+'; out[o + 3 + L] = 10; out[o + 4 + 2 * L] = 10; }
-        for (u64 k = lane; k < L; k += 64) {
-            out[o + 1 + k] = bases[b + k];
-            out[o + 4 + L + k] = quals[b + k];
-        }
+        if (sub == 0) { out[o] = 10; out[o + 1 + L] = 10; out[o + 2 + L] = (u8)'+'; out[o + 3 + L] = 10; out[o + 4 + 2 * L] = 10; }
+        copy_bytes(out + o + 1, bases + b, L, sub, 16);
+        copy_bytes(out + o + 4 + L, quals + b, L, sub, 16);
     }
 }
 
@@ -223,8 +236,7 @@ void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq)
     fq->bases = c->alloc<u8>(fq->total + 64);
     fq->quals = c->alloc<u8>(fq->total + 64);
     if (N) {
-        u64 waves = N < (1u << 18) ? N : (1u << 18);
-        KLAUNCH(c, K_FASTQ, 4.0 * (double)fq->total, k_fq_gather, ceil_div(waves, 4), 256, d_fastq, (const FqRec *)fq->rec,
+        KLAUNCH(c, K_FASTQ, 4.0 * (double)fq->total, k_fq_gather, bfq_grid(N, 16), 256, d_fastq, (const FqRec *)fq->rec,
                 (const u64 *)fq->roff, N, fq->bases, fq->quals);
     }
     fq->lineEnd = lineEnd;
@@ -258,8 +270,7 @@ u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     c->sync();
     u8 *out = c->alloc<u8>(outLen + 64);
     if (N) {
-        u64 waves = N < (1u << 18) ? N : (1u << 18);
-        KLAUNCH(c, K_FASTQ, 2.0 * (double)outLen, k_fq_format, ceil_div(waves, 4), 256, d_bases, d_quals, d_roff,
+        KLAUNCH(c, K_FASTQ, 2.0 * (double)outLen, k_fq_format, bfq_grid(N, 16), 256, d_bases, d_quals, d_roff,
                 mode ? d_hdr : (const u8 *)nullptr, (const u64 *)hStart, (const u32 *)hLen, (const u64 *)recOff, N, out, lines ? 1 : 0);
     }
     *d_out = out;

@@ -4,7 +4,10 @@ coverage, empty and one-base reads) under random parameters (-k -m -v -f -t, M 0
     python tests/soak_gpu.py <seconds> <first seed>
 tests/test_gpu_parity.py::test_randomised_shapes_and_parameters runs the first cases of it.  Round 1: 33 363 cases /
 8.96 G rows in nine runs (one of them with BFQ_HUGE_CAP=20000, i.e. batching and the one-workgroup fallback of the
-huge-segment rounds), all bit-exact (eBWT, permuted QS, LCP, output reads, statistics, bfq_int mode)."""
+huge-segment rounds), all bit-exact (eBWT, permuted QS, LCP, output reads, statistics, bfq_int mode).
+Round 2 adds per case: step 1 in one piece or pile by pile (drawn at random; BFQ_PILES_SPLIT=1 in the environment splits
+every pile again), bfq_int mode = LCP deduced from the BWT alone (k_bfs.hip), on small cases also with the ties of
+identical suffixes shuffled, and the FASTQ job (text in, FASTQ text + streams out) against the oracle's reads."""
 import sys, time, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -67,7 +70,8 @@ def run_case(eng, O, seed):
     b, q, r = gen(rng)
     par = dict(k=int(rng.integers(1, 40)), m=int(rng.integers(1, 9)), v=int(rng.integers(33, 100)), f=int(rng.integers(34, 101)),
                t=int(rng.integers(0, 45)), M=int(rng.integers(0, 4)), B=int(rng.integers(0, 2)))
-    eng.set_params(**par)
+    piles = int(rng.integers(0, 2))
+    eng.set_params(piles=piles, **par)
     p = O.params(K=par["k"], m=par["m"], v=par["v"], f=par["f"], t=par["t"], M=par["M"], B=par["B"])
     bwt, qs, lcp = O.build_ebwt(b, q, r)
     gb, gq, gl = eng.build_ebwt(b, q, r)
@@ -78,7 +82,18 @@ def run_case(eng, O, seed):
     if len(bwt):
         sb, sq, sroff, sst = eng.smooth_invert(bwt, qs)
         ok = ok and np.array_equal(sb, ob) and np.array_equal(sq, oq) and np.array_equal(sroff, r)
-    return ok, len(bwt), "seed %d %s reads %d rows %d" % (seed, par, len(r) - 1, len(bwt))
+    if 0 < len(bwt) <= 4000:                                  # any tie order: the reference sees one terminator symbol
+        tb, tq = util.shuffle_ties(bwt, qs, rng)
+        eb, eq, eroff, est = O.smooth_invert(tb, tq, None, p)
+        sb, sq, sroff, sst = eng.smooth_invert(tb, tq)
+        ok = ok and np.array_equal(sb, eb) and np.array_equal(sq, eq) and np.array_equal(sroff, eroff) and all(est[k] == sst[k] for k in est)
+    if len(bwt) <= 200000:                                    # FASTQ text in -> FASTQ text + line streams out
+        from bfqzip_amd import fastq
+        text = fastq.format_fastq(b, q, r)
+        res = eng.fastq_job([text], fastq=True, streams=True)
+        ok = ok and res.fastq.tobytes() == fastq.format_fastq(ob, oq, r) and res.dna.tobytes() == fastq.format_lines(ob, r) \
+            and res.qs.tobytes() == fastq.format_lines(oq, r)
+    return ok, len(bwt), "seed %d %s piles %d reads %d rows %d" % (seed, par, piles, len(r) - 1, len(bwt))
 
 
 def main(seconds, seed0):
