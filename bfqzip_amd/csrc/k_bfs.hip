@@ -30,7 +30,6 @@
 //   rank block (64 B, rows [64 b, 64 b + 64)): u64 count of A, C, G, N, T before the block, then the
 //   three bit planes of the rows' symbol codes (# 0, A 1, C 2, G 3, N 4, T 5).
 //   queue entry: lb (38 bits) | (rb - lb) (25 bits) | leaf (1 bit); longer intervals go to a small side list.
-#include <algorithm>
 #include "bfq_internal.h"
 #include "bfq_device.h"
 
@@ -213,111 +212,6 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
     if (lane == 0 && wsum) atomicAdd((unsigned long long *)&a.tail[3], (unsigned long long)wsum);
 }
 
-// ---- the same level in ROW ORDER ------------------------------------------------------------------------------------
-// The order in which a level's intervals are processed does not matter for the result, but it decides the access pattern:
-// taken as they were appended, every rank block, LCP probe and LCP store is a random access (54 G random sectors/s, 21.6 G
-// random 2-byte stores/s on this chip).  Sorted by lb they sweep the arrays front to back -- and the order comes for free:
-// the children of one symbol c keep their parents' order (LF is monotone inside a symbol) and the symbols' row ranges
-// follow one another (F[A] < F[C] < ...), so five per-symbol output streams, concatenated, are the next level sorted.
-// Ordered appends need positions before the writes: the level runs twice over its queue segment -- k_bfs_sorted<0> counts
-// the children per workgroup slice and symbol (read-only: a boundary is probed by exactly one interval per level, so the
-// count sees what the second run sees), a scan turns the counts into offsets, k_bfs_sorted<1> claims, fills and writes.
-// The few intervals of the side list are expanded by k_bfs_level<true> afterwards and append behind (best effort).
-#define BQ_SLICE 2048                                        // queue entries per workgroup (8 rounds of 256)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_bfs_sorted(BfsArgs a, u64 qbeg, u64 qend, u32 level, int cur, u32 *__restrict__ cntWG,
-                                                     const u64 *__restrict__ offWG, u64 numWG)
-{
-    __shared__ u64 sh[4];
-    const u32 lane = bfq_lane();
-    u64 written = 0;
-    for (u64 g = blockIdx.x; g < numWG; g += gridDim.x) {
-        u64 usedP = 0;                                         // packed per-symbol counts of the rounds done (12 bits each; uniform)
-        u64 myP = 0;                                           // MODE 0: this thread's packed counts
-        u64 base[5];
-        if (MODE == 1) {
-#pragma unroll
-            for (int c = 0; c < 5; c++) base[c] = qend + offWG[(u64)c * numWG + g];
-        }
-        for (u32 rd = 0; rd < BQ_SLICE / 256; rd++) {
-            const u64 i = qbeg + g * BQ_SLICE + (u64)rd * 256 + threadIdx.x;
-            const bool valid = i < qend;
-            u64 lb = 0, rb = 0;
-            bool leaf = false;
-            if (valid) { const u64 e = __builtin_nontemporal_load(a.queue + i); lb = e & BQ_LB_MASK; rb = lb + ((e >> BQ_LB_BITS) & BQ_LEN_MAX); leaf = (e & BQ_LEAF) != 0; }
-            u64 P = 0;                                         // packed flags: symbol c's child goes to the queue
-            u64 kid[5];
-            u64 flb = 0, frb = 0;
-            if (valid) {
-                u64 ol[5], orr[5];
-                {
-                    const u64 bl = lb >> 6, br = (rb + 1) >> 6;
-                    const RankBlk B0 = load_blk(a.rank, bl);
-                    occ5(B0, lb, ol);
-                    if (br == bl) occ5(B0, rb + 1, orr);
-                    else { const RankBlk B1 = load_blk(a.rank, br); occ5(B1, rb + 1, orr); }
-                }
-                u64 nlb[5], nrb[5];
-                u32 probe[5];
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    nlb[c] = a.F[c + 1] + ol[c]; nrb[c] = a.F[c + 1] + orr[c] - 1;
-                    probe[c] = (orr[c] > ol[c]) ? (u32)a.lcp[nrb[c] + 1] : 0u;
-                }
-#pragma unroll
-                for (int c = 0; c < 5; c++) {
-                    if (orr[c] > ol[c]) {
-                        const bool claim = probe[c] == LCP_UNSET;
-                        const bool wide = leaf && nrb[c] > nlb[c];
-                        const bool fits = nrb[c] - nlb[c] <= BQ_LEN_MAX;
-                        if ((claim || wide) && fits) { P |= 1ull << (12 * c); kid[c] = nlb[c] | ((nrb[c] - nlb[c]) << BQ_LB_BITS) | (leaf ? BQ_LEAF : 0ull); }
-                        if (MODE == 1) {
-                            if (claim) { a.lcp[nrb[c] + 1] = (u16)level; written++; }
-                            if (wide) {
-                                const u64 inner = nrb[c] - nlb[c];
-                                written += inner;
-                                if (inner <= 2) { a.lcp[nlb[c] + 1] = (u16)level; a.lcp[nrb[c]] = (u16)level; }
-                                else if (inner <= BQ_FILL_INLINE && frb == flb) { flb = nlb[c]; frb = nrb[c]; }
-                                else if (inner <= BQ_FILL_INLINE) { for (u64 p = nlb[c] + 1; p <= nrb[c]; p++) a.lcp[p] = (u16)level; }
-                                else {
-                                    const u64 k = atomicAdd((unsigned long long *)&a.tail[4], 1ull);
-                                    if (k < a.fillCap) { a.fill[2 * k] = nlb[c]; a.fill[2 * k + 1] = nrb[c]; }
-                                }
-                            }
-                            if ((claim || wide) && !fits) {
-                                const u64 k = atomicAdd((unsigned long long *)&a.tail[1 + (cur ^ 1)], 1ull);
-                                if (k < a.sideCap) { a.side[cur ^ 1][2 * k] = nlb[c]; a.side[cur ^ 1][2 * k + 1] = nrb[c] | (leaf ? BQ_LEAF : 0ull); }
-                            }
-                        }
-                    }
-                }
-            }
-            if (MODE == 0) { myP += P; continue; }
-            for (u64 pend = __ballot(frb > flb); pend; pend &= pend - 1) {
-                const int src = __builtin_ctzll(pend);
-                const u64 l0 = bfq_readlane64(flb, src), r0 = bfq_readlane64(frb, src);
-                if (l0 + 1 + lane <= r0) a.lcp[l0 + 1 + lane] = (u16)level;
-            }
-            u64 totP;
-            const u64 exP = bfq_block_exscan64(P, sh, &totP) + usedP;
-#pragma unroll
-            for (int c = 0; c < 5; c++)
-                if ((P >> (12 * c)) & 1ull) __builtin_nontemporal_store(kid[c], a.queue + base[c] + ((exP >> (12 * c)) & 0xFFFull));
-            usedP += totP;
-        }
-        if (MODE == 0) {
-            u64 totP;
-            (void)bfq_block_exscan64(myP, sh, &totP);
-            if (threadIdx.x < 5) cntWG[(u64)threadIdx.x * numWG + g] = (u32)((totP >> (12 * threadIdx.x)) & 0xFFFull);
-        }
-    }
-    if (MODE == 1) {
-        const u64 wsum = bfq_readlane64(bfq_wave_incscan64(written), 63);
-        if (lane == 0 && wsum) atomicAdd((unsigned long long *)&a.tail[3], (unsigned long long)wsum);
-    }
-}
-__global__ void k_bfs_settail(u64 *tail, u64 qend, const u64 *total) { tail[0] = qend + *total; }
-
 // inner boundaries of the long leaf blocks listed by the level kernel
 __global__ __launch_bounds__(256) void k_bfs_fill(BfsArgs a, u64 count, u32 level)
 {
@@ -379,10 +273,6 @@ void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lc
     a.side[0] = c->alloc<u64>(2 * a.sideCap); a.side[1] = c->alloc<u64>(2 * a.sideCap);
     a.fillCap = n / (BQ_FILL_INLINE + 1) + 16;                     // listed blocks are disjoint and hold more than BQ_FILL_INLINE rows each
     a.fill = c->alloc<u64>(2 * a.fillCap);
-    const bool sorted = !getenv("BFQ_BFS_UNSORTED");            // levels in row order (k_bfs_sorted) or as appended (k_bfs_level)
-    u32 *cntWG = c->alloc<u32>(5 * (n / BQ_SLICE + 2));
-    u64 *offWG = c->alloc<u64>(5 * (n / BQ_SLICE + 2) + 8);
-    u64 *d_tot = c->alloc<u64>(2);
     HIP_CHECK(hipMemsetAsync(lcp, 0xFF, 2 * (n + 1), c->stream));
     KLAUNCH(c, K_BFS, 2.0 * (double)N, k_bfs_init, bfq_grid(N + 1, 256), 256, a, N);
     u64 t[5] = {0, 0, 0, 0, 0};
@@ -394,14 +284,7 @@ void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lc
         if (level > BFQ_MAX_READ_LEN + 2) throw BfqError{BFQ_E_TOO_LONG, "LCP beyond BFQ_MAX_READ_LEN (or not an eBWT)"};
         HIP_CHECK(hipMemsetAsync(a.tail + 1 + (cur ^ 1), 0, 8, c->stream));
         // per interval: two 64-B rank blocks, per child one LCP probe + store, 8 B of queue in and out
-        if (qend > qbeg && sorted) {
-            const u64 numWG = ceil_div(qend - qbeg, BQ_SLICE);
-            const unsigned grid = (unsigned)std::min<u64>(numWG, 1u << 18);
-            KLAUNCH(c, K_BFS, 80.0 * (double)(qend - qbeg), k_bfs_sorted<0>, grid, 256, a, qbeg, qend, level, cur, cntWG, (const u64 *)offWG, numWG);
-            bfq_exscan_u32(c, cntWG, offWG, 5 * numWG, d_tot);
-            KLAUNCH(c, K_BFS, 160.0 * (double)(qend - qbeg), k_bfs_sorted<1>, grid, 256, a, qbeg, qend, level, cur, cntWG, (const u64 *)offWG, numWG);
-            hipLaunchKernelGGL(k_bfs_settail, dim3(1), dim3(1), 0, c->stream, a.tail, qend, (const u64 *)d_tot);
-        } else if (qend > qbeg)
+        if (qend > qbeg)
             KLAUNCH(c, K_BFS, 160.0 * (double)(qend - qbeg), k_bfs_level<false>, bfq_grid(qend - qbeg, 256 * 8), 256, a, qbeg, qend, level, cur);
         if (nside) KLAUNCH(c, K_BFS, 0.0, k_bfs_level<true>, bfq_grid(nside, 256), 256, a, 0ull, 0ull, level, cur);
         HIP_CHECK(hipMemcpyAsync(t, a.tail, 40, hipMemcpyDeviceToHost, c->stream));
