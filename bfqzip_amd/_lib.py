@@ -18,6 +18,7 @@ SYMBOLS = [
     "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_fastq_run_streams",
     "bfq_smooth_invert_fastq", "bfq_fastq_run_job", "bfq_host_alloc", "bfq_host_free",
     "bfq_text_count_lines", "bfq_text_nth_newline", "bfq_fastq_build_ebwt_fd", "bfq_smooth_invert_fastq_fd",
+    "bfq_glob_begin", "bfq_glob_local_text", "bfq_glob_pile_counts", "bfq_glob_init_out", "bfq_glob_run_pile", "bfq_glob_finish",
     "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device", "bfq_synth_fastq",
     "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
     "bfq_workspace_bytes", "bfq_version",
@@ -114,6 +115,12 @@ def lib():
         L.bfq_smooth_invert_fastq.argtypes = [vp, vp, vp, vp, C.c_int, u64, vp, u64, vp, u64, C.POINTER(u64),
                                               C.POINTER(Stats)]
         L.bfq_fastq_run_job.argtypes = [vp, C.POINTER(FastqJob), C.POINTER(Stats)]
+        L.bfq_glob_begin.argtypes = [vp, C.POINTER(TextPart), C.c_int, C.POINTER(u64), C.POINTER(u64)]
+        L.bfq_glob_local_text.argtypes = [vp, vp, vp]
+        L.bfq_glob_pile_counts.argtypes = [vp, vp, u64, vp]
+        L.bfq_glob_init_out.argtypes = [vp, vp, vp, u64, vp, vp]
+        L.bfq_glob_run_pile.argtypes = [vp, vp, vp, u64, C.c_int, C.c_int, vp, vp, C.POINTER(Stats)]
+        L.bfq_glob_finish.argtypes = [vp, vp, vp, C.POINTER(FastqJob)]
         L.bfq_host_alloc.restype = vp
         L.bfq_host_alloc.argtypes = [u64]
         L.bfq_host_free.argtypes = [vp]

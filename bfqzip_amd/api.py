@@ -254,6 +254,63 @@ class Engine:
         r.stats = st.as_dict()
         return r
 
+    # ---- global mode (one collection over several GPUs, unsharded result): the per-GPU pieces; tensors are torch
+    #      uint8 tensors on this engine's device (bfqzip_amd/parallel.py run_global drives them)
+    tensor_device = "cuda"
+
+    def glob_begin(self, parts):
+        arrs = [_u8(p) for p in parts]
+        tp = (_lib.TextPart * max(len(arrs), 1))()
+        for i, a in enumerate(arrs):
+            tp[i].data = a.ctypes.data if len(a) else None
+            tp[i].len = len(a)
+        N = C.c_uint64(0); T = C.c_uint64(0)
+        self._ck(self.L.bfq_glob_begin(self.h, tp, len(arrs), C.byref(N), C.byref(T)))
+        return int(N.value), int(T.value)
+
+    def glob_local_text(self, t8, q8):
+        self._ck(self.L.bfq_glob_local_text(self.h, t8.data_ptr(), q8.data_ptr()))
+
+    def glob_pile_counts(self, t8, n):
+        cnt = np.zeros(36, np.uint64)
+        self._ck(self.L.bfq_glob_pile_counts(self.h, t8.data_ptr() if n else None, n, _ptr(cnt)))
+        return cnt.reshape(6, 6)
+
+    def glob_init_out(self, t8, q8, n, sym, qual):
+        self._ck(self.L.bfq_glob_init_out(self.h, t8.data_ptr(), q8.data_ptr(), n, sym.data_ptr(), qual.data_ptr()))
+
+    def glob_run_pile(self, t8, q8, n, s, s2, sym, qual):
+        st = _lib.Stats()
+        self._ck(self.L.bfq_glob_run_pile(self.h, t8.data_ptr(), q8.data_ptr(), n, s, s2, sym.data_ptr(), qual.data_ptr(), C.byref(st)))
+        return st.as_dict()
+
+    def glob_finish(self, dna, qs, keep_headers=False, fastq=True, streams=False, hdr=False, text_len=0):
+        """dna / qs: this block's line streams (torch uint8, device).  Returns a JobResult like fastq_job."""
+        J = _lib.FastqJob()
+        J.nparts = 0; J.keep_headers = 1 if keep_headers else 0
+        sl = int(dna.numel())
+        bf = np.empty(text_len + 32, np.uint8) if fastq else None
+        bd = np.empty(sl + 16, np.uint8) if streams else None
+        bq = np.empty(sl + 16, np.uint8) if streams else None
+        bh = np.empty(text_len + 16, np.uint8) if hdr else None
+        if bf is not None:
+            J.out_fastq = bf.ctypes.data; J.cap_fastq = len(bf)
+        if bd is not None:
+            J.out_dna = bd.ctypes.data; J.out_qs = bq.ctypes.data; J.cap_stream = len(bd)
+        if bh is not None:
+            J.out_hdr = bh.ctypes.data; J.cap_hdr = len(bh)
+        self._ck(self.L.bfq_glob_finish(self.h, dna.data_ptr() if sl else None, qs.data_ptr() if sl else None, C.byref(J)))
+        r = JobResult()
+        r.fastq = bf[:J.fastq_len] if bf is not None else None
+        r.dna = bd[:J.stream_len] if bd is not None else None
+        r.qs = bq[:J.stream_len] if bq is not None else None
+        r.hdr = bh[:J.hdr_len] if bh is not None else None
+        r.n_reads, r.total_bases = int(J.n_reads), int(J.total_bases)
+        r.part_reads = [0, r.n_reads]; r.part_fastq_off = [0, int(J.fastq_len)]
+        r.part_stream_off = [0, int(J.stream_len)]; r.part_hdr_off = [0, int(J.hdr_len)]
+        r.stats = {}
+        return r
+
     def smooth_invert_fastq(self, bwt, qs, lcp=None, headers=None):
         """bfq_int / bfq_ext writing the FASTQ text; headers = bytes of the -H file or None."""
         bwt = np.ascontiguousarray(bwt, np.uint8); qs = np.ascontiguousarray(qs, np.uint8)

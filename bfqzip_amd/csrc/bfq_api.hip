@@ -302,7 +302,9 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
     u64 *text3 = c->alloc<u64>(nwords);
     SortRec A, B;
-    A.w0 = c->alloc<u32>(n + 16); A.w12 = c->alloc<u64>(n + 16);
+    A.w12 = c->alloc<u64>(n + 16);
+    const size_t mKeep = c->mark();                     // position mode keeps the text and the records' (w1, w2) words
+    A.w0 = c->alloc<u32>(n + 16);
     size_t mB = c->mark();
     B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16);
     u8 *T8 = (u8 *)B.w0, *Q8 = (u8 *)B.w12;             // dead before the sort's first scatter
@@ -313,7 +315,8 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     c->release(mB);                                     // the big-segment list reuses the B buffers
     bfq_refine(c, A, text3, n, c->d_lcp, st);
     bfq_emit_bwt(c, A, n, termOut, c->d_bwt, c->d_qual, c->d_gcnt);
-    c->release(m0);
+    if (c->keepRecs) { c->release(mKeep); c->d_w12 = A.w12; c->d_text3 = text3; c->keepMark = m0; }
+    else c->release(m0);
 }
 
 // ---------------------------------------------------------------- steps 2-4
@@ -393,6 +396,47 @@ static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_
     }
 }
 
+// ---- the fused path without LF table and walks ("position mode", device-resident entry point only).
+// When step 1 has just run, every row still knows the text position of its suffix (the sort payload), so steps 3-4 need
+// neither LF(row) nor an inversion: the outputs start as a copy of the input (qualities binned when B = 1) in line-stream
+// layout, k_cluster writes its edits straight to the position each row stands for, and the terminators are dropped
+// again at the end.  What it trades: k_lf_build + k_invert (one random 64-byte sector per base) against one random
+// byte store per EDITED base or quality (bfq_params / BFQ_POSMODE; measured in DESIGN.md 4).
+__global__ __launch_bounds__(256) void k_lines_init(const u8 *__restrict__ bases, const u8 *__restrict__ quals, const u64 *__restrict__ roff, u64 N,
+                                                    int B, u8 *__restrict__ dna, u8 *__restrict__ qs)
+{
+    const u32 sub = threadIdx.x & 15u;
+    const u64 ngrp = ((u64)gridDim.x * blockDim.x) >> 4;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < N; i += ngrp) {
+        const u64 b = roff[i], len = roff[i + 1] - b, o = b + i;
+        for (u64 k = sub; k < len; k += 16) { dna[o + k] = bases[b + k]; const u32 q = quals[b + k]; qs[o + k] = (u8)(B ? bfq_bin8(q) : q); }
+        if (sub == 0) { dna[o + len] = 10; qs[o + len] = 10; }
+    }
+}
+__global__ __launch_bounds__(256) void k_lines_strip(const u8 *__restrict__ dna, const u8 *__restrict__ qs, const u64 *__restrict__ roff, u64 N,
+                                                     u8 *__restrict__ bases, u8 *__restrict__ quals)
+{
+    const u32 sub = threadIdx.x & 15u;
+    const u64 ngrp = ((u64)gridDim.x * blockDim.x) >> 4;
+    for (u64 i = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < N; i += ngrp) {
+        const u64 b = roff[i], len = roff[i + 1] - b, o = b + i;
+        for (u64 k = sub; k < len; k += 16) { bases[b + k] = dna[o + k]; quals[b + k] = qs[o + k]; }
+    }
+}
+static void steps34_positions(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals)
+{
+    const u64 n = c->n, N = c->N;
+    if (!n) return;
+    u8 *dna = c->alloc<u8>(n + 64), *qs = c->alloc<u8>(n + 64);
+    if (N) KLAUNCH(c, K_MISC, 4.0 * (double)(n - N), k_lines_init, bfq_grid(N, 16), 256, d_bases, d_quals, d_roff, N, c->P.B, dna, qs);
+    u8 *in = c->alloc<u8>(n + 64);
+    bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
+    ClusterPos pm{c->d_w12, c->d_text3, dna, qs, c->P.B};
+    RankIndex none{nullptr, n};
+    bfq_clusters(c, none, c->d_bwt, c->d_qual, in, n, &pm);
+    if (N) KLAUNCH(c, K_MISC, 4.0 * (double)(n - N), k_lines_strip, bfq_grid(N, 16), 256, (const u8 *)dna, (const u8 *)qs, d_roff, N, d_out_bases, d_out_quals);
+}
+
 extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_quals,
                                     const uint64_t *d_read_off, uint64_t N, uint64_t total, uint8_t *d_out_bases,
                                     uint8_t *d_out_quals, bfq_stats *st)
@@ -401,8 +445,12 @@ extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const ui
         if (st) memset(st, 0, sizeof *st);
         reserve_step1(c, total + N, N, 0);
         c->zeroCounters();
+        const bool posMode = !c->piles && getenv("BFQ_POSMODE") && atoi(getenv("BFQ_POSMODE"));
+        c->keepRecs = posMode;
         bfq_step1_device(c, d_bases, d_quals, (const u64 *)d_read_off, N, total, c->P.term, st);
-        steps234_device(c, (u64 *)d_read_off, d_out_bases, d_out_quals);
+        c->keepRecs = false;
+        if (posMode) steps34_positions(c, d_bases, d_quals, (const u64 *)d_read_off, d_out_bases, d_out_quals);
+        else steps234_device(c, (u64 *)d_read_off, d_out_bases, d_out_quals);
         c->fetchCounters();
         c->profCollect();
         check_counters(c);
@@ -567,6 +615,7 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
 u64 bfq_fastq_count_lines(bfq_ctx *c, const u8 *d_buf, u64 len);   // k_fastq.hip
 u8 *bfq_ctx::textBuf(size_t bytes)
 {
+    residentValid = false;                                      // whoever asks is about to overwrite the buffer
     if (bytes > textCap) {
         if (d_text) { HIP_CHECK(hipStreamSynchronize(stream)); HIP_CHECK(hipFree(d_text)); d_text = nullptr; textCap = 0; }
         size_t want = (bytes + (bytes >> 4) + 0xFFFFF) & ~(size_t)0xFFFFF;

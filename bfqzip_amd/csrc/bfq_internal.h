@@ -86,6 +86,9 @@ struct bfq_ctx {
     int gcntTerm = -1;              // terminator byte those counts were taken with
     u64 n = 0, N = 0;
     bool piles = false;             // step 1 runs pile by pile (k_piles.hip): set by the reservation of the current call
+    bool keepRecs = false;          // step 1 leaves the packed text and the sorted records' (w1, w2) words in the arena (position mode)
+    const u64 *d_w12 = nullptr, *d_text3 = nullptr;
+    size_t keepMark = 0;
 
     // profiling
     bool profOn = true;
@@ -115,6 +118,8 @@ struct bfq_ctx {
     u8 *d_text = nullptr;
     size_t textCap = 0;
     u8 *textBuf(size_t bytes);
+    u64 residentLen = 0;            // global mode: length of the block text bfq_glob_begin left in d_text
+    bool residentValid = false;
 };
 // a host-side operand of a transfer: memory, or an open file at an offset (the front-ends' files)
 struct HostRef {
@@ -175,13 +180,21 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
 // the same, one first-symbol pile at a time (k_piles.hip); workspace bound for pile records of at most `cap` rows
 void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, int termOut, bfq_stats *st);
 size_t bfq_ws_need_piles(u64 n, u64 N, u64 cap, u64 extra);
+// one pile on its own (global mode): pile-local eBWT / QS / LCP + the sorted records' (w1, w2) words, all in the arena
+struct PileRows { u64 m; u8 *bwt, *qs; u16 *lcp; const u64 *w12; };
+u64 bfq_run_one_pile(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u32 s, u32 s2, int termOut, PileRows *out);
+void bfq_pile_pair_counts(bfq_ctx *c, const u8 *T8, u64 n, u64 *counts36);
+void bfq_pack_text(bfq_ctx *c, const u8 *T8, u64 n, u64 *text3, u64 nwords);
 
 // steps 2-4 pieces
 RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int term, const u32 *gcnt = nullptr);
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in);
 // LCP array from the eBWT alone (k_bfs.hip): lcp has n + 1 entries
 void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp, u32 *gcntOut = nullptr);   // gcntOut: [6][n/256+1] symbol counts, kept
-void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n);
+// pm != nullptr: position mode -- no LF table (R.lfq may be null): edits go to the output line streams at the text position
+// each row's sort record carries (k_cluster.hip)
+struct ClusterPos { const u64 *w12; const u64 *text3; u8 *outSym, *outQual; int B; };
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, const ClusterPos *pm = nullptr);
 // LF walks: lengths only, then emission at given offsets
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);
 void bfq_fixed_offsets(bfq_ctx *c, u64 N, u64 L, u64 *d_roff);   // d_roff[i] = i * L, i <= N

@@ -63,6 +63,13 @@ struct ClusterArgs {
     const double *qthr;     // [qthrN] decreasing: smallest x with round(-10*log10(x)) <= qthrLo+k
     int qthrLo, qthrN;
     DevCounters *cnt;
+    // position mode (w12 != nullptr): the rows still carry their sort records, so every row knows the text position of
+    // its suffix; edits go straight to the output line streams at that position, the symbol before the preceding one
+    // comes from the packed text instead of bwt[LF(row)].  No LF table is needed (R.lfq == nullptr).
+    const u64 *w12;         // the records' (w1, w2) words in row order: position of the row's suffix in the terminated text
+    const u64 *text3;       // packed text (bfq_common.h)
+    u8 *outSym, *outQual;   // OUT.fq.dna / OUT.fq.qs layout = terminated text coordinates (read i at roff[i] + i, then '\n')
+    int B;
     u64 *bigStart;          // first in() rows of the clusters left to the k_big_* kernels
     struct BigState *big;   // their state
     u16 *firstOut;          // per CL_WROWS rows: first row with in() == 0 (CL_WROWS: none), for k_big_extent
@@ -78,13 +85,30 @@ __device__ __forceinline__ u8 dna5(int i) { return (u8)((0x4E54474341ull >> (8 *
 // replaces the entry's quality byte, a replaced base sets the flag and the replacement
 // code (reference: QUAL[j]=..., rankbv_setbit + BWT_MOD.push_back, bfq_int.cpp:386-391).
 // a.qual[] keeps the original permuted qualities (read only).
+__device__ __forceinline__ u64 row_pos(const ClusterArgs &a, u64 j)      // text position of row j's suffix
+{
+    const u64 x = a.w12[j];
+    return bfq_val_pos(bfq_rec_pay((u32)x, (u32)(x >> 32)));
+}
 __device__ __forceinline__ void set_qual(const ClusterArgs &a, u64 j, int newqs)
 {
-    lfq_set_qual(a.R.lfq, j, (u32)newqs & 0xFFu);
+    if (a.w12) { const u32 q = (u32)newqs & 0xFFu; a.outQual[row_pos(a, j) - 1] = (u8)(a.B ? bfq_bin8(q) : q); }
+    else lfq_set_qual(a.R.lfq, j, (u32)newqs & 0xFFu);
 }
 __device__ __forceinline__ void set_mod(const ClusterArgs &a, u64 j, u8 sym)
 {
-    lfq_set_repl(a.R.lfq, j, bfq_base_code(a.bwt[j]), bfq_base_code(sym));
+    if (a.w12) a.outSym[row_pos(a, j) - 1] = sym;
+    else lfq_set_repl(a.R.lfq, j, bfq_base_code(a.bwt[j]), bfq_base_code(sym));
+}
+// the symbol that precedes the eBWT symbol of row j: bwt[LF(j)] (bfq_int.cpp:545-560,577); row j holds a base
+__device__ __forceinline__ u8 prec_sym(const ClusterArgs &a, u64 j)
+{
+    if (!a.w12) return a.bwt[lfq_next(a.R.lfq[j])];
+    const u64 p = row_pos(a, j);                               // bwt[j] = text[p - 1], the one before it text[p - 2]
+    if (p < 2) return (u8)a.term;
+    const u64 t = p - 2, w = t / BFQ_SYMS_PER_WORD;
+    const u32 code = (u32)(a.text3[w] >> (3u * (20u - (u32)(t - w * BFQ_SYMS_PER_WORD)))) & 7u;
+    return code ? bfq_code_sym(code) : (u8)a.term;
 }
 
 // bfq_int.cpp:376-405 modBasesSmoothQS
@@ -192,8 +216,7 @@ __device__ __forceinline__ bool process_cluster_body(const ClusterArgs &a, u64 s
         u8 b = a.bwt[j];
         int w = (b == Freq[0]) ? 0 : ((b == Freq[1]) ? 1 : -1);
         if (w < 0) continue;
-        u64 nx = lfq_next(a.R.lfq[j]);
-        u8 ch = a.bwt[nx];
+        u8 ch = prec_sym(a, j);
         if (ch != TERM && ch != 'N') { fr[w] |= 1u << ord5(ch); symbPrec[w] = ch; }
     }
     if (__popc(fr[0] & 15u) == 1 && __popc(fr[1] & 15u) == 1 && symbPrec[0] != symbPrec[1]) {   // :568
@@ -202,7 +225,7 @@ __device__ __forceinline__ bool process_cluster_body(const ClusterArgs &a, u64 s
             u8 b = a.bwt[j];
             if (b == TERM) continue;
             if (b != Freq[0] && b != Freq[1] && !((lowQS >> ord5(b)) & 1u)) {
-                u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
+                u8 ch = prec_sym(a, j);
                 if (ch == symbPrec[0]) { set_mod(a, j, Freq[0]); st.modb++; }
                 else if (ch == symbPrec[1]) { set_mod(a, j, Freq[1]); st.modb++; }
             } else if (b == Freq[0] || b == Freq[1]) {
@@ -465,7 +488,7 @@ __global__ __launch_bounds__(256) void k_big_prec(ClusterArgs a)
         u32 f0 = 0, f1 = 0;
         CB_FOR_ROWS(
             if (b == s0 || b == s1) {
-                const u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
+                const u8 ch = prec_sym(a, j);
                 if (ch != TERM && ch != 'N') { if (b == s0) f0 |= 1u << ord5(ch); else f1 |= 1u << ord5(ch); }
             })
         if (f0) atomicOr(&S.fr0, f0);
@@ -497,7 +520,7 @@ __global__ __launch_bounds__(256) void k_big_apply(ClusterArgs a)
                 CB_FOR_ROWS(
                     if (b != TERM) {
                         if (b != s0 && b != s1 && !((lowQS >> ord5(b)) & 1u)) {
-                            const u8 ch = a.bwt[lfq_next(a.R.lfq[j])];
+                            const u8 ch = prec_sym(a, j);
                             if (ch == p0) { set_mod(a, j, s0); modb++; }
                             else if (ch == p1) { set_mod(a, j, s1); modb++; }
                         } else if (b == s0 || b == s1) { set_qual(a, j, newqs); qs++; }
@@ -515,11 +538,13 @@ void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
     KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, bfq_grid((n + 7) / 8, 256), 256, lcp, n, K, in);
 }
 
-void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n)
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, const ClusterPos *pm)
 {
     if (!n) return;
     ClusterArgs a;
     a.R = R; a.bwt = bwt; a.qual = qual; a.in = in; a.n = n;
+    a.w12 = pm ? pm->w12 : nullptr; a.text3 = pm ? pm->text3 : nullptr;
+    a.outSym = pm ? pm->outSym : nullptr; a.outQual = pm ? pm->outQual : nullptr; a.B = pm ? pm->B : 0;
     a.m = c->P.m; a.v = c->P.v; a.f = c->P.f; a.t = c->P.t; a.term = c->P.term & 0xFF; a.M = c->P.M; a.ext = c->P.ext;
     a.powtab = c->d_powtab; a.qthr = c->d_qthr; a.qthrLo = c->qthrLo; a.qthrN = c->qthrN;
     a.cnt = c->d_cnt;

@@ -241,3 +241,58 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     }
     c->release(m0);
 }
+
+// ---- one pile on its own (global mode, k_global.hip): the pile (first symbol s, second symbol s2 or 7 = any) of the text
+// T8 / Q8 / text3 is sorted and refined into pile-local arrays; the sorted records' (w1, w2) words stay for the caller
+// (every row knows the text position of its suffix).  Everything lives in the arena above the caller's mark.
+u64 bfq_run_one_pile(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u32 s, u32 s2, int termOut, PileRows *out)
+{
+    const u64 nb = ceil_div(n, PB);
+    u32 *cntBlk = c->alloc<u32>(6 * nb);
+    u64 *blkOff = c->alloc<u64>(6 * nb + 8);
+    u64 *d_tot = c->alloc<u64>(8);
+    const u32 want = (s2 == 7u) ? s : s2;
+    KLAUNCH(c, K_KEYS, (double)n, k_pile_count, bfq_grid(nb, 1), 256, T8, n, (s2 == 7u) ? 7u : s, cntBlk, nb);
+    bfq_exscan_u32(c, cntBlk + (u64)want * nb, blkOff, nb, d_tot);
+    u64 m = 0;
+    HIP_CHECK(hipMemcpyAsync(&m, d_tot, 8, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    out->m = m;
+    if (!m) return 0;
+    out->bwt = c->alloc<u8>(m + 64); out->qs = c->alloc<u8>(m + 64); out->lcp = c->alloc<u16>(m + 64);
+    SortRec A, B;
+    A.w12 = c->alloc<u64>(m + 16);
+    const size_t mKeep = c->mark();
+    A.w0 = c->alloc<u32>(m + 16);
+    const size_t mB = c->mark();
+    B.w0 = c->alloc<u32>(m + 16); B.w12 = c->alloc<u64>(m + 16);
+    KLAUNCH(c, K_KEYS, 1.3 * (double)n + 12.0 * (double)m, k_build_keys_pile, bfq_grid(nb, 1), 256, T8, Q8, text3, n, s, s2, (const u64 *)blkOff, A, nb);
+    bfq_radix_sort(c, A, B, m, 6, nullptr);
+    c->release(mB);
+    hipLaunchKernelGGL(k_refine_reset, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
+    bfq_refine(c, A, text3, m, out->lcp, nullptr);
+    bfq_emit_bwt(c, A, m, termOut, out->bwt, out->qs, nullptr);
+    c->release(mKeep);
+    out->w12 = A.w12;
+    return m;
+}
+
+// suffix counts by (first, second) symbol: counts[6 * s + s2]; row s = 0 holds the N terminator suffixes in counts[0]
+void bfq_pile_pair_counts(bfq_ctx *c, const u8 *T8, u64 n, u64 *counts36)
+{
+    const size_t mk = c->mark();
+    const u64 nb = ceil_div(n, PB);
+    u32 *cntBlk = c->alloc<u32>(6 * nb);
+    u64 *off = c->alloc<u64>(6 * nb + 8);
+    u64 *d_tot = c->alloc<u64>(40);
+    for (u32 f = 0; f <= 5; f++) {
+        KLAUNCH(c, K_KEYS, (double)n, k_pile_count, bfq_grid(nb, 1), 256, T8, n, f == 0 ? 7u : f, cntBlk, nb);
+        for (int q = 0; q < 6; q++) bfq_exscan_u32(c, cntBlk + (u64)q * nb, off, nb, d_tot + 6 * f + q);
+    }
+    HIP_CHECK(hipMemcpyAsync(counts36, d_tot, 36 * 8, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    const u64 N = counts36[0];                                   // f == 0 counted single symbols: [#, A, C, G, N, T]
+    for (int q = 1; q < 6; q++) counts36[q] = 0;
+    counts36[0] = N;
+    c->release(mk);
+}

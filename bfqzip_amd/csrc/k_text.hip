@@ -157,6 +157,11 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
 }
 
 
+void bfq_pack_text(bfq_ctx *c, const u8 *T8, u64 n, u64 *text3, u64 nwords)
+{
+    KLAUNCH(c, K_PACK, (double)n + 8.0 * (double)nwords, k_pack3, bfq_grid(nwords, 256), 256, T8, n, text3, nwords);
+}
+
 void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0)
 {
     if (!n) return;

@@ -70,6 +70,30 @@ class Comm:
         if self.dist is not None and self.world > 1:
             self.dist.barrier()
 
+    def _direct(self, t):
+        return self.dist is not None and self.dist.get_backend() == "nccl" and t.is_cuda
+
+    def broadcast_(self, t, src):
+        """In-place broadcast of a tensor (RCCL on GPU tensors; through the host under gloo)."""
+        if self.dist is None or self.world == 1 or t.numel() == 0:
+            return
+        if self._direct(t) or not t.is_cuda:
+            self.dist.broadcast(t, src)
+        else:
+            h = t.cpu()
+            self.dist.broadcast(h, src)
+            t.copy_(h)
+
+    def all_reduce_sum_(self, t):
+        if self.dist is None or self.world == 1 or t.numel() == 0:
+            return
+        if self._direct(t) or not t.is_cuda:
+            self.dist.all_reduce(t)
+        else:
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+
 
 def map_file(path):
     """Read-only uint8 view of a file (nothing is read until touched)."""
@@ -208,6 +232,90 @@ def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fas
     return tot
 
 
+def deal_piles(counts, world):
+    """The two-symbol piles (first 1..5, second 1..5; a second symbol 0 = suffixes of one base: never in a cluster) dealt to
+    the ranks, largest first to the least loaded rank: [[(s, s2), ...] per rank] -- the same list on every rank."""
+    piles = sorted(((int(counts[s][s2]), s, s2) for s in range(1, 6) for s2 in range(1, 6) if counts[s][s2]), reverse=True)
+    load = [0] * world
+    mine = [[] for _ in range(world)]
+    for cnt, s, s2 in piles:
+        r = min(range(world), key=lambda k: (load[k], k))
+        load[r] += cnt
+        mine[r].append((s, s2))
+    return mine
+
+
+def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_streams=False, want_hdr=False, log=None):
+    """ONE collection over all ranks with the result of the unsharded run (k_global.hip): every rank parses its share of the
+    file, the terminated text is exchanged, the two-symbol piles of the global eBWT are dealt to the ranks, the edits are
+    combined with one all-reduce, and every rank writes its own reads.  Single-end input."""
+    import torch
+    dev = torch.device(eng.tensor_device)
+    host = eng.host
+    buf = map_file(inputs[0])
+    idx = TextIndex(buf, comm, host.text_line_counts, host.text_nth_newline)
+    if idx.num_lines % 4:
+        raise ValueError("FASTQ: number of lines is not a multiple of 4")
+    R, W, r = idx.num_lines // 4, comm.world, comm.rank
+    b0, b1 = idx.line_start(4 * (R * r // W)), idx.line_start(4 * (R * (r + 1) // W))
+    N_loc, tot_loc = eng.glob_begin([buf[b0:b1]])
+    sz = comm.all_gather_i64(np.array([N_loc, tot_loc, b1 - b0], np.int64))
+    rows = sz[:, 0] + sz[:, 1]
+    base = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
+    n = int(base[-1])
+    t8 = torch.empty(max(n, 1), dtype=torch.uint8, device=dev); q8 = torch.empty_like(t8)
+    lo, hi = int(base[r]), int(base[r + 1])
+    if hi > lo:
+        eng.glob_local_text(t8[lo:hi], q8[lo:hi])
+    for src in range(W):                                             # every rank ends up with the whole text
+        comm.broadcast_(t8[int(base[src]):int(base[src + 1])], src)
+        comm.broadcast_(q8[int(base[src]):int(base[src + 1])], src)
+    tot = {"blocks": 1, "reads": N_loc, "bases": tot_loc, "stats": {}}
+    sym = torch.empty_like(t8); qual = torch.empty_like(t8)
+    if n:
+        counts = eng.glob_pile_counts(t8, n)
+        mine = deal_piles(counts, W)[r]
+        eng.glob_init_out(t8, q8, n, sym, qual)
+        osym, oqual = sym.clone(), qual.clone()
+        for s, s2 in mine:
+            st = eng.glob_run_pile(t8, q8, n, s, s2, sym, qual)
+            for key, v in st.items():
+                if not key.startswith("n_"):
+                    tot["stats"][key] = tot["stats"].get(key, 0) + v
+            if log:
+                log(f"pile {'#ACGNT'[s]}{'#ACGNT'[s2]}: {st['n_rows']} rows, {st['num_clust']} clusters")
+        del t8, q8
+        sym ^= osym; qual ^= oqual                                   # what this rank's piles changed (zero elsewhere)
+        comm.all_reduce_sum_(sym); comm.all_reduce_sum_(qual)
+        dna = osym[lo:hi] ^ sym[lo:hi]; qs = oqual[lo:hi] ^ qual[lo:hi]
+        del sym, qual, osym, oqual
+    else:
+        dna = torch.empty(0, dtype=torch.uint8, device=dev); qs = dna.clone()
+    res = eng.glob_finish(dna, qs, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr, text_len=int(b1 - b0))
+    # outputs at their final offsets: one block per rank, in rank order
+    kinds = [k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w]
+    if comm.rank == 0:
+        for k in kinds:
+            open(names[0][k], "wb").close()
+    comm.barrier()
+    data = {"fastq": res.fastq, "dna": res.dna, "qs": res.qs, "hdr": res.hdr}
+    sizes = np.array([len(data[k]) if k in kinds else 0 for k in KINDS], np.int64)
+    allsz = comm.all_gather_i64(sizes)
+    before = allsz[:comm.rank].sum(axis=0)
+    for ki, kind in enumerate(KINDS):
+        if kind in kinds:
+            fd = os.open(names[0][kind], os.O_WRONLY)
+            if sizes[ki]:
+                os.pwrite(fd, memoryview(data[kind]), int(before[ki]))
+            os.close(fd)
+    comm.barrier()
+    keys = sorted(tot["stats"]) if tot["stats"] else ["num_clust", "num_clust_discarded", "num_clust_amb_discarded", "num_clust_mod",
+                                                     "num_clust_alleq", "bases_inside", "qs_smoothed", "modified"]
+    allst = comm.all_gather_i64(np.array([tot["stats"].get(k, 0) for k in keys], np.int64))
+    tot["stats_all_ranks"] = {k: int(v) for k, v in zip(keys, allst.sum(axis=0))}
+    return tot
+
+
 def main(argv=None):
     """`python -m torch.distributed.run --nproc-per-node G -m bfqzip_amd.parallel in.fastq [in2.fastq -p] -o OUT -t n [-H]`
 
@@ -233,6 +341,8 @@ def main(argv=None):
     ap.add_argument("--m3", action="store_true", help="--m2 plus OUT.h, headers kept (BFQzip.py:60-64,192-201)")
     ap.add_argument("--streams-only", action="store_true", help="with --m2/--m3: do not write the merged FASTQ text")
     ap.add_argument("--pinned", action="store_true", help="page-locked output buffers (direct DMA)")
+    ap.add_argument("--global", dest="glob", action="store_true",
+                    help="ONE eBWT over the whole input, its piles dealt to the GPUs: the result of the unsharded run (single-end; -t ignored)")
     ap.add_argument("--M", type=int, default=2); ap.add_argument("--B", type=int, default=0)
     a = ap.parse_args(argv)
     if a.paired and len(a.input) != 2:
@@ -263,8 +373,15 @@ def main(argv=None):
         pins = {k: api.PinnedBuffer(cap) for k in (["fastq"] if not a.streams_only else []) + (["dna", "qs"] if streams else []) + (["hdr"] if a.m3 else [])}
         bufs = {k: p.array for k, p in pins.items()}
     log = (lambda m: print(f"[rank {comm.rank}] {m}", flush=True)) if a.v else None
-    tot = run_files(eng, comm, a.input, a.threads, names, paired=a.paired, headers=a.headers,
-                    want_fastq=not (streams and a.streams_only), want_streams=streams, want_hdr=a.m3, out_bufs=bufs, log=log)
+    if a.glob:
+        if a.paired:
+            print("=== ERROR ===\n--global takes one input file", file=sys.stderr)
+            return 1
+        tot = run_global(eng, comm, a.input, names, headers=a.headers, want_fastq=not (streams and a.streams_only),
+                         want_streams=streams, want_hdr=a.m3, log=log)
+    else:
+        tot = run_files(eng, comm, a.input, a.threads, names, paired=a.paired, headers=a.headers,
+                        want_fastq=not (streams and a.streams_only), want_streams=streams, want_hdr=a.m3, out_bufs=bufs, log=log)
     if a.v:
         print(f"[rank {comm.rank}] {tot}", flush=True)
     eng.close()

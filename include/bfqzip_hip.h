@@ -165,6 +165,26 @@ typedef struct bfq_fastq_job {
 } bfq_fastq_job;
 int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *job, bfq_stats *st);
 
+/* ---- one collection over several GPUs with the UNSHARDED result (opt-in; not in the reference, whose parallel driver
+ * gives up the clusters that span blocks, README.md:107).  The per-GPU pieces; bfqzip_amd/parallel.py --global holds the
+ * device buffers (torch tensors) and runs the collectives.  d_ = device pointers.
+ *   bfq_glob_begin      : upload and parse this rank's block; its text stays resident in the context
+ *   bfq_glob_local_text : the block as terminated text: symbol codes (# 0, A 1, C 2, G 3, N 4, T 5) and qualities,
+ *                         total_bases + n_reads bytes each -> exchanged so that every rank holds the whole text (n bytes)
+ *   bfq_glob_pile_counts: counts36[6 s + s2] = suffixes that start with symbols s, s2 (row 0: the terminator suffixes)
+ *   bfq_glob_init_out   : line-stream copy of the whole text (letters / qualities, '\n' at the terminators)
+ *   bfq_glob_run_pile   : sort + refine the pile (s, s2) of the global eBWT, cluster analysis, edits written to d_sym / d_qual
+ *                         at the text position each row stands for; statistics of this pile in *st
+ *   bfq_glob_finish     : this block's line streams (after the exchange) -> FASTQ text / streams as in bfq_fastq_run_job
+ *                         (job->parts ignored; qualities are binned here when B = 1) */
+int bfq_glob_begin(bfq_ctx *c, const bfq_text_part *parts, int nparts, uint64_t *n_reads, uint64_t *total_bases);
+int bfq_glob_local_text(bfq_ctx *c, uint8_t *d_T8, uint8_t *d_Q8);
+int bfq_glob_pile_counts(bfq_ctx *c, const uint8_t *d_T8, uint64_t n, uint64_t *counts36);
+int bfq_glob_init_out(bfq_ctx *c, const uint8_t *d_T8, const uint8_t *d_Q8, uint64_t n, uint8_t *d_sym, uint8_t *d_qual);
+int bfq_glob_run_pile(bfq_ctx *c, const uint8_t *d_T8, const uint8_t *d_Q8, uint64_t n, int s, int s2,
+                      uint8_t *d_sym, uint8_t *d_qual, bfq_stats *st);
+int bfq_glob_finish(bfq_ctx *c, uint8_t *d_dna, uint8_t *d_qs, bfq_fastq_job *job);
+
 /* Pinned (page-locked) host memory for the buffers above. */
 void *bfq_host_alloc(uint64_t bytes);
 void  bfq_host_free(void *p);

@@ -98,3 +98,33 @@ def test_paired_m1_streams_3M_reads_two_ranks(orc, tmp_path):
             assert np.array_equal(outs[o]["qs"][s0:s0 + hi - lo], ref.qs[lo:hi]), (k, o, "qs")
             lo, hi = ref.part_hdr_off[o], ref.part_hdr_off[o + 1]
             assert np.array_equal(outs[o]["hdr"][hoff:hoff + hi - lo], ref.hdr[lo:hi]), (k, o, "hdr")
+
+
+def test_global_mode_gives_the_unsharded_result(tmp_path):
+    """--global: ONE eBWT over the whole input, its two-symbol piles dealt to the ranks (k_global.hip, position-mode clusters),
+    edits combined by an all-reduce: the result must be that of the unsharded run -- the reference's own md5 on its example
+    (SURVEY App. B), and the single-engine result on 200 k synthetic reads (M=1, B=1, headers, two-frequent-symbol sites)."""
+    from bfqzip_amd import api, parallel
+    out = str(tmp_path / "G")
+    for world in (1, 2):
+        _launch(world, [EXAMPLE, "-o", out, "--global", "-v", "1"], str(tmp_path))
+        assert md5file(out + ".fastq") == "29866da058baf8e382927c0023e8ab12"
+    _launch(2, [EXAMPLE, "-o", out, "--global", "--m3"], str(tmp_path))
+    assert md5file(out + ".fastq") == "9178301c8ef6c9864d5ebfccf47313d4"                 # = bfq_int -H (SURVEY App. B)
+    check_streams(parallel.output_names([EXAMPLE], out, False), [EXAMPLE])
+    f = str(tmp_path / "syn.fastq")
+    b, q, r = api.synth_host(api.synth_spec(200_000, 30, Lmax=70, seed=99, coverage=40, err_ppm=20000, n_ppm=8000, snp_every=97, dsnp_every=131))
+    from bfqzip_amd import fastq
+    idx = np.arange(len(r) - 1)
+    h = fastq.HeaderSpans.from_list([x.encode() for x in np.char.add("@R", idx.astype(str)).tolist()])
+    open(f, "wb").write(fastq.format_fastq(b, q, r, h))
+    eng = api.Engine(0, m=5, M=1, B=1)
+    ref = eng.fastq_job([open(f, "rb").read()], keep_headers=True, fastq=True, streams=True, hdr=True)
+    assert ref.stats["num_clust_mod"] > 0 and ref.stats["modified"] > 0
+    want = {"fastq": ref.fastq.tobytes(), "dna": ref.dna.tobytes(), "qs": ref.qs.tobytes(), "hdr": ref.hdr.tobytes()}
+    eng.close()
+    for world in (1, 2):
+        _launch(world, [f, "-o", out, "--global", "--m3", "--M", "1", "--B", "1"], str(tmp_path))
+        nm = parallel.output_names([f], out, False)[0]
+        for k in want:
+            assert open(nm[k], "rb").read() == want[k], (world, k)

