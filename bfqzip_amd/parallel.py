@@ -249,16 +249,26 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
     """ONE collection over all ranks with the result of the unsharded run (k_global.hip): every rank parses its share of the
     file, the terminated text is exchanged, the two-symbol piles of the global eBWT are dealt to the ranks, the edits are
     combined with one all-reduce, and every rank writes its own reads.  Single-end input."""
+    import time
     import torch
     dev = torch.device(eng.tensor_device)
     host = eng.host
+    tm = {}
+    t_last = [time.perf_counter()]
+
+    def lap(name):
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+        now = time.perf_counter(); tm[name] = round(tm.get(name, 0.0) + now - t_last[0], 4); t_last[0] = now
     buf = map_file(inputs[0])
     idx = TextIndex(buf, comm, host.text_line_counts, host.text_nth_newline)
     if idx.num_lines % 4:
         raise ValueError("FASTQ: number of lines is not a multiple of 4")
     R, W, r = idx.num_lines // 4, comm.world, comm.rank
     b0, b1 = idx.line_start(4 * (R * r // W)), idx.line_start(4 * (R * (r + 1) // W))
+    lap("index")
     N_loc, tot_loc = eng.glob_begin([buf[b0:b1]])
+    lap("upload+parse")
     sz = comm.all_gather_i64(np.array([N_loc, tot_loc, b1 - b0], np.int64))
     rows = sz[:, 0] + sz[:, 1]
     base = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
@@ -270,7 +280,8 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
     for src in range(W):                                             # every rank ends up with the whole text
         comm.broadcast_(t8[int(base[src]):int(base[src + 1])], src)
         comm.broadcast_(q8[int(base[src]):int(base[src + 1])], src)
-    tot = {"blocks": 1, "reads": N_loc, "bases": tot_loc, "stats": {}}
+    lap("text exchange")
+    tot = {"blocks": 1, "reads": N_loc, "bases": tot_loc, "stats": {}, "seconds": tm}
     sym = torch.empty_like(t8); qual = torch.empty_like(t8)
     if n:
         counts = eng.glob_pile_counts(t8, n)
@@ -285,10 +296,12 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
             if log:
                 log(f"pile {'#ACGNT'[s]}{'#ACGNT'[s2]}: {st['n_rows']} rows, {st['num_clust']} clusters")
         del t8, q8
+        lap("piles")
         sym ^= osym; qual ^= oqual                                   # what this rank's piles changed (zero elsewhere)
         comm.all_reduce_sum_(sym); comm.all_reduce_sum_(qual)
         dna = osym[lo:hi] ^ sym[lo:hi]; qs = oqual[lo:hi] ^ qual[lo:hi]
         del sym, qual, osym, oqual
+        lap("delta all-reduce")
     else:
         dna = torch.empty(0, dtype=torch.uint8, device=dev); qs = dna.clone()
     res = eng.glob_finish(dna, qs, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr, text_len=int(b1 - b0))
@@ -309,6 +322,7 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
                 os.pwrite(fd, memoryview(data[kind]), int(before[ki]))
             os.close(fd)
     comm.barrier()
+    lap("format+write")
     keys = sorted(tot["stats"]) if tot["stats"] else ["num_clust", "num_clust_discarded", "num_clust_amb_discarded", "num_clust_mod",
                                                      "num_clust_alleq", "bases_inside", "qs_smoothed", "modified"]
     allst = comm.all_gather_i64(np.array([tot["stats"].get(k, 0) for k in keys], np.int64))

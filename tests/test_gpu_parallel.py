@@ -112,6 +112,13 @@ def test_global_mode_gives_the_unsharded_result(tmp_path):
     _launch(2, [EXAMPLE, "-o", out, "--global", "--m3"], str(tmp_path))
     assert md5file(out + ".fastq") == "9178301c8ef6c9864d5ebfccf47313d4"                 # = bfq_int -H
     check_streams(parallel.output_names([EXAMPLE], out, False), [EXAMPLE])
+    # fewer reads than ranks (an empty block), an empty file
+    one = str(tmp_path / "one.fastq"); open(one, "wb").write(b"@x\nACGTTGCA\n+\nIIIIIIII\n")
+    _launch(2, [one, "-o", out, "--global"], str(tmp_path))
+    assert open(out + ".fastq", "rb").read() == b"@\nACGTTGCA\n+\nIIIIIIII\n"
+    nil = str(tmp_path / "nil.fastq"); open(nil, "wb").close()
+    _launch(2, [nil, "-o", out, "--global"], str(tmp_path))
+    assert open(out + ".fastq", "rb").read() == b""
     f = str(tmp_path / "syn.fastq")
     b, q, r = api.synth_host(api.synth_spec(200_000, 30, Lmax=70, seed=99, coverage=40, err_ppm=20000, n_ppm=8000, snp_every=97, dsnp_every=131))
     from bfqzip_amd import fastq
