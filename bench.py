@@ -162,6 +162,31 @@ def ebwt_modes(api, eng, text, N, L, log):
     return res
 
 
+def global_mode(api, parallel, eng, text, N, L, dna_ref, qs_ref, log):
+    """parallel.py --global on this one GPU: the collection as ONE eBWT whose two-symbol piles are sorted one
+    after the other, position-mode clusters, streams written to /dev/shm -- the per-rank work of the multi-GPU global mode,
+    all of it on one rank.  Its streams must equal those of the fused path (e2e_host): parity at full size."""
+    d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        with open(d + "/in.fastq", "wb") as f:
+            mv = memoryview(text)
+            for o in range(0, len(mv), 1 << 30):
+                f.write(mv[o:o + (1 << 30)])
+        names = parallel.output_names([d + "/in.fastq"], d + "/G", False)
+        t0 = time.perf_counter()
+        tot = parallel.run_global(eng, parallel.Comm(), [d + "/in.fastq"], names, want_fastq=False, want_streams=True)
+        dt = time.perf_counter() - t0
+        same = bool(np.array_equal(np.fromfile(names[0]["dna"], np.uint8), dna_ref) and np.array_equal(np.fromfile(names[0]["qs"], np.uint8), qs_ref))
+        log(f"global mode: {dt:.2f}s {tot['seconds']} parity={same}")
+        return {"wall_s": round(dt, 3), "Mbases_per_s": round(N * L / 1e6 / dt, 1), "seconds": tot["seconds"], "streams_equal_fused_path": same,
+                "what": "parallel.run_global, 1 rank: file on /dev/shm -> upload, parse, text, 25 piles sorted one by one, position-mode clusters, "
+                        "streams written to /dev/shm; compared with e2e_host's streams"}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def dropin_wall(text, N, L, params, log):
     """`gsufsort in.fastq --bwt --qs -o OUT` then `bfq_int -e OUT.bwt -q OUT.bwt.qs -o OUT.fq -m 5` (BFQzip.py:184,215-222)
     with the drop-in executables on /dev/shm files; wall seconds per tool (process start, file I/O, PCIe, GPU work)."""
@@ -173,7 +198,9 @@ def dropin_wall(text, N, L, params, log):
     try:
         t0 = time.perf_counter()
         with open(d + "/in.fastq", "wb") as f:
-            f.write(memoryview(text))
+            mv = memoryview(text)
+            for o in range(0, len(mv), 1 << 30):
+                f.write(mv[o:o + (1 << 30)])
         t1 = time.perf_counter()
         env = dict(os.environ, BFQ_M=str(params["M"]), BFQ_B=str(params["B"]))
         subprocess.check_call([gs, d + "/in.fastq", "--bwt", "--qs", "-o", d + "/OUT"], stdout=subprocess.DEVNULL, env=env, timeout=1200)
@@ -346,6 +373,8 @@ def main():
                     text = pin.array[:tlen]
                 except Exception as e:                       # e.g. pinned memory refused: reported, not fatal
                     res["e2e_host"] = {"error": f"{type(e).__name__}: {e}"}
+            if not args.no_e2e and text is not None and "error" not in res.get("e2e_host", {}):
+                res["global_mode"] = global_mode(api, parallel, eng, text, Nw, L, outs["dna"].array[:Nw * (L + 1)], outs["qs"].array[:Nw * (L + 1)], log)
             if not args.no_e2e:
                 try:
                     for v in outs.values():

@@ -95,6 +95,14 @@ class Comm:
             t.copy_(h)
 
 
+def pwrite_all(fd, data, offset):
+    """os.pwrite until everything is written (one call moves at most 0x7ffff000 bytes on Linux)."""
+    mv = memoryview(data).cast("B")
+    done = 0
+    while done < len(mv):
+        done += os.pwrite(fd, mv[done:done + (1 << 30)], offset + done)
+
+
 def map_file(path):
     """Read-only uint8 view of a file (nothing is read until touched)."""
     if os.path.getsize(path) == 0:
@@ -223,8 +231,7 @@ def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fas
                 for ki, kind in enumerate(KINDS):
                     if kind in kinds and sizes[o, ki]:
                         lo = cut[kind][o]
-                        os.pwrite(fds[(o, kind)], memoryview(data[kind][lo:lo + int(sizes[o, ki])]),
-                                  int(cursor[o, ki] + before[o, ki]))
+                        pwrite_all(fds[(o, kind)], data[kind][lo:lo + int(sizes[o, ki])], int(cursor[o, ki] + before[o, ki]))
         cursor += allsz.sum(axis=0)[:nout]
     for fd in fds.values():
         os.close(fd)
@@ -319,7 +326,7 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
         if kind in kinds:
             fd = os.open(names[0][kind], os.O_WRONLY)
             if sizes[ki]:
-                os.pwrite(fd, memoryview(data[kind]), int(before[ki]))
+                pwrite_all(fd, data[kind], int(before[ki]))
             os.close(fd)
     comm.barrier()
     lap("format+write")

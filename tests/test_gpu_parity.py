@@ -301,7 +301,8 @@ def test_full_size_properties(engine):
       3. B=1 (configs[2] itself): bases as in 2., qualities = Illumina-binned qualities of 2.;
       4. M=1 (configs[4]'s smoothing): same base edits and same smoothed positions as 2. (the decision tree does not
          depend on M), qualities differ only there;
-      5. bfq_int mode (LCP deduced from the eBWT alone) on the 4.53 G-row eBWT of run 2: same reads as run 2."""
+      5. bfq_int mode (LCP deduced from the eBWT alone) on the 4.53 G-row eBWT of run 2: same reads as run 2;
+      2b. step 1 pile by pile: same reads and statistics as run 2."""
     torch = pytest.importorskip("torch")
     free, total = torch.cuda.mem_get_info()
     if free < 200 * 2**30:
@@ -343,6 +344,11 @@ def test_full_size_properties(engine):
     assert int(iroff[-1]) == tot and bool((np.diff(iroff.astype(np.int64)) == L).all())
     del ib, iq, changed_b, changed_q
     ob2 = ob.clone(); oq2 = oq.clone()
+    # 2b. step 1 pile by pile (k_piles.hip) at full size: the same reads
+    engine.set_params(k=16, m=5, M=2, B=0, v=ord(">"), piles=1)
+    stp = run(); torch.cuda.synchronize()
+    assert {k: stp[k] for k in st if k != "n_big_segments"} == {k: st[k] for k in st if k != "n_big_segments"}
+    assert torch.equal(ob, ob2) and torch.equal(oq, oq2)
     # 3. B = 1
     engine.set_params(k=16, m=5, M=2, B=1, v=ord(">"))
     stb = run(); torch.cuda.synchronize()
