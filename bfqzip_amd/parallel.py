@@ -372,12 +372,18 @@ def main(argv=None):
     if a.m3:
         a.headers = True
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+    if torch.cuda.device_count():
+        torch.cuda.set_device(local)                                 # tensors of the global mode and RCCL use the engine's GPU
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(os.environ.get("BFQ_BACKEND", "nccl"))
-    local = int(os.environ.get("LOCAL_RANK", "0")) % max(1, torch.cuda.device_count())
+        backend = os.environ.get("BFQ_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local) if (dist and dist.get_backend() == "nccl") else None
     comm = Comm(dist, dev)
     par = dict(m=5, M=a.M, B=a.B)                                    # -m 5: what BFQzip.py passes (BFQzip.py:215)

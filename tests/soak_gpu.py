@@ -7,7 +7,8 @@ tests/test_gpu_parity.py::test_randomised_shapes_and_parameters runs the first c
 huge-segment rounds), all bit-exact (eBWT, permuted QS, LCP, output reads, statistics, bfq_int mode).
 Round 2 adds per case: step 1 in one piece or pile by pile (drawn at random; BFQ_PILES_SPLIT=1 in the environment splits
 every pile again), bfq_int mode = LCP deduced from the BWT alone (k_bfs.hip), on small cases also with the ties of
-identical suffixes shuffled, and the FASTQ job (text in, FASTQ text + streams out) against the oracle's reads."""
+identical suffixes shuffled, the FASTQ job (text in, FASTQ text + streams out) against the oracle's reads, and the global mode
+(parallel.run_global on one rank: two-symbol piles, position-mode clusters) against the same."""
 import sys, time, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -93,6 +94,15 @@ def run_case(eng, O, seed):
         res = eng.fastq_job([text], fastq=True, streams=True)
         ok = ok and res.fastq.tobytes() == fastq.format_fastq(ob, oq, r) and res.dna.tobytes() == fastq.format_lines(ob, r) \
             and res.qs.tobytes() == fastq.format_lines(oq, r)
+        if par["k"] >= 2 and len(r) > 1:                         # global mode (one eBWT dealt pile by pile, position-mode clusters) = the same reads
+            import tempfile
+            from bfqzip_amd import parallel
+            with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
+                open(d + "/in.fastq", "wb").write(text)
+                names = parallel.output_names([d + "/in.fastq"], d + "/G", False)
+                tot = parallel.run_global(eng, parallel.Comm(), [d + "/in.fastq"], names)
+                ok = ok and open(names[0]["fastq"], "rb").read() == res.fastq.tobytes() \
+                    and all(tot["stats_all_ranks"][k] == st[k] for k in ("num_clust", "qs_smoothed", "modified", "num_clust_mod", "bases_inside"))
     return ok, len(bwt), "seed %d %s piles %d reads %d rows %d" % (seed, par, piles, len(r) - 1, len(bwt))
 
 

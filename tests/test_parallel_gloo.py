@@ -86,6 +86,18 @@ def test_paired_blocks_rule(orc, tmp_path):
     assert md5file(names[0]["fastq"]) == MD5_P1 and md5file(names[1]["fastq"]) == MD5_P2
 
 
+def test_pile_dealing_is_deterministic_and_balanced():
+    cnt = np.zeros((6, 6), np.uint64)
+    rng = np.random.default_rng(3)
+    cnt[1:, 1:] = rng.integers(1, 1000, (5, 5))
+    cnt[4, :] = 0                                                   # no suffix starts with N
+    for world in (1, 2, 3, 8):
+        a, b = parallel.deal_piles(cnt, world), parallel.deal_piles(cnt.copy(), world)
+        assert a == b and sorted(p for r in a for p in r) == sorted((s, s2) for s in (1, 2, 3, 5) for s2 in range(1, 6))
+        loads = [sum(int(cnt[s][s2]) for s, s2 in r) for r in a]
+        assert max(loads) - min(loads) <= int(cnt.max())             # largest-first to the least loaded rank
+
+
 def test_global_mode_equals_the_unsharded_run(orc, tmp_path):
     """--global (bfqzip_amd.parallel.run_global, single process): one eBWT over the whole file = the unsharded reference
     run (example/reads.fastq, M2B0 -m 5 -> 29866da0...), and with headers = the -H run (9178301c...)."""
