@@ -264,9 +264,9 @@ class Engine:
         for i, a in enumerate(arrs):
             tp[i].data = a.ctypes.data if len(a) else None
             tp[i].len = len(a)
-        N = C.c_uint64(0); T = C.c_uint64(0)
-        self._ck(self.L.bfq_glob_begin(self.h, tp, len(arrs), C.byref(N), C.byref(T)))
-        return int(N.value), int(T.value)
+        N = (C.c_uint64 * len(arrs))(); T = (C.c_uint64 * len(arrs))()
+        self._ck(self.L.bfq_glob_begin(self.h, tp, len(arrs), N, T))
+        return [int(x) for x in N], [int(x) for x in T]                  # reads / bases of every part
 
     def glob_local_text(self, t8, q8):
         self._ck(self.L.bfq_glob_local_text(self.h, t8.data_ptr(), q8.data_ptr()))
@@ -284,7 +284,7 @@ class Engine:
         self._ck(self.L.bfq_glob_run_pile(self.h, t8.data_ptr(), q8.data_ptr(), n, s, s2, sym.data_ptr(), qual.data_ptr(), C.byref(st)))
         return st.as_dict()
 
-    def glob_finish(self, dna, qs, keep_headers=False, fastq=True, streams=False, hdr=False, text_len=0):
+    def glob_finish(self, dna, qs, keep_headers=False, fastq=True, streams=False, hdr=False, text_len=0, nparts=1):
         """dna / qs: this block's line streams (torch uint8, device).  Returns a JobResult like fastq_job."""
         J = _lib.FastqJob()
         J.nparts = 0; J.keep_headers = 1 if keep_headers else 0
@@ -306,8 +306,10 @@ class Engine:
         r.qs = bq[:J.stream_len] if bq is not None else None
         r.hdr = bh[:J.hdr_len] if bh is not None else None
         r.n_reads, r.total_bases = int(J.n_reads), int(J.total_bases)
-        r.part_reads = [0, r.n_reads]; r.part_fastq_off = [0, int(J.fastq_len)]
-        r.part_stream_off = [0, int(J.stream_len)]; r.part_hdr_off = [0, int(J.hdr_len)]
+        r.part_reads = [int(J.part_reads[i]) for i in range(nparts + 1)]
+        r.part_fastq_off = [int(J.part_fastq_off[i]) for i in range(nparts + 1)]
+        r.part_stream_off = [int(J.part_stream_off[i]) for i in range(nparts + 1)]
+        r.part_hdr_off = [int(J.part_hdr_off[i]) for i in range(nparts + 1)]
         r.stats = {}
         return r
 

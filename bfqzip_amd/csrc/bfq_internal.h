@@ -120,6 +120,8 @@ struct bfq_ctx {
     u8 *textBuf(size_t bytes);
     u64 residentLen = 0;            // global mode: length of the block text bfq_glob_begin left in d_text
     bool residentValid = false;
+    int residentParts = 0;          // ... and where its parts start (entry residentParts = residentLen)
+    u64 residentPstart[BFQ_MAX_PARTS + 1] = {0, 0, 0, 0, 0};
 };
 // a host-side operand of a transfer: memory, or an open file at an offset (the front-ends' files)
 struct HostRef {

@@ -54,10 +54,13 @@ static void reparse(bfq_ctx *c, DevFastq *fq, size_t extra)
     bfq_fastq_parse(c, c->d_text, len, fq);
 }
 
+void bfq_fastq_part_index(bfq_ctx *c, const DevFastq *fq, const u64 *h_pstart, int nparts, u64 *d_idx);   // k_fastq.hip
+void bfq_pick_u64(bfq_ctx *c, const u64 *d_src, const u64 *d_idx, int count, u64 addIdx, u64 *d_out);      // k_fastq.hip
+
 extern "C" int bfq_glob_begin(bfq_ctx *c, const bfq_text_part *parts, int nparts, uint64_t *n_reads, uint64_t *total_bases)
 {
     return guarded_g(c, [&] {
-        if (nparts < 0 || nparts > BFQ_MAX_PARTS || (nparts && !parts)) throw BfqError{BFQ_E_ARG, "0..BFQ_MAX_PARTS parts"};
+        if (nparts < 1 || nparts > BFQ_MAX_PARTS || !parts) throw BfqError{BFQ_E_ARG, "1..BFQ_MAX_PARTS parts"};
         u64 len = 0;
         std::vector<u8> addNl(nparts, 0);
         for (int p = 0; p < nparts; p++) {
@@ -68,16 +71,27 @@ extern "C" int bfq_glob_begin(bfq_ctx *c, const bfq_text_part *parts, int nparts
         u8 *d = c->textBuf(len + 64);
         u64 o = 0;
         for (int p = 0; p < nparts; p++) {
+            c->residentPstart[p] = o;
             bfq_upload(c, d + o, parts[p].data, parts[p].len);
             o += parts[p].len;
             if (addNl[p]) { HIP_CHECK(hipMemsetAsync(d + o, '\n', 1, c->stream)); o++; }
         }
-        c->residentLen = len; c->residentValid = true;
+        c->residentPstart[nparts] = len;
+        c->residentLen = len; c->residentValid = true; c->residentParts = nparts;
         DevFastq fq;
         reparse(c, &fq, 0);
+        // reads and bases of every part (n_reads / total_bases: nparts entries each)
+        u64 *d_pidx = c->alloc<u64>(nparts + 1), *d_pb = c->alloc<u64>(nparts + 1);
+        bfq_fastq_part_index(c, &fq, c->residentPstart, nparts, d_pidx);
+        bfq_pick_u64(c, fq.roff, d_pidx, nparts + 1, 0, d_pb);
+        u64 hidx[BFQ_MAX_PARTS + 1], hb[BFQ_MAX_PARTS + 1];
+        HIP_CHECK(hipMemcpyAsync(hidx, d_pidx, 8 * (nparts + 1), hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpyAsync(hb, d_pb, 8 * (nparts + 1), hipMemcpyDeviceToHost, c->stream));
         c->fetchCounters();
-        if (n_reads) *n_reads = fq.N;
-        if (total_bases) *total_bases = fq.total;
+        for (int p = 0; p < nparts; p++) {
+            if (n_reads) n_reads[p] = hidx[p + 1] - hidx[p];
+            if (total_bases) total_bases[p] = hb[p + 1] - hb[p];
+        }
     });
 }
 
@@ -176,12 +190,9 @@ __global__ __launch_bounds__(256) void k_bin_lines(u8 *__restrict__ qs, u64 n)
     }
 }
 
-void bfq_fastq_part_index(bfq_ctx *c, const DevFastq *fq, const u64 *h_pstart, int nparts, u64 *d_idx);   // k_fastq.hip
-void bfq_pick_u64(bfq_ctx *c, const u64 *d_src, const u64 *d_idx, int count, u64 addIdx, u64 *d_out);      // k_fastq.hip
-
 // d_dna / d_qs: this block's line streams after the exchange (qualities not binned yet; d_qs is binned in place when B = 1).
-// Outputs as in bfq_fastq_run_job (job->parts / nparts are ignored: the resident block text supplies headers and lengths;
-// part offsets are reported for one part).
+// Outputs as in bfq_fastq_run_job (job->parts / nparts are ignored: the resident block text supplies headers, lengths and
+// the parts whose shares of every output are reported).
 extern "C" int bfq_glob_finish(bfq_ctx *c, uint8_t *d_dna, uint8_t *d_qs, bfq_fastq_job *J)
 {
     return guarded_g(c, [&] {
@@ -192,13 +203,23 @@ extern "C" int bfq_glob_finish(bfq_ctx *c, uint8_t *d_dna, uint8_t *d_qs, bfq_fa
         J->n_reads = fq.N; J->total_bases = fq.total;
         J->fastq_len = J->stream_len = J->hdr_len = 0;
         if (c->P.B && sl) KLAUNCH(c, K_MISC, 2.0 * (double)sl, k_bin_lines, bfq_grid(sl, 256), 256, d_qs, sl);
+        const int np = c->residentParts;
+        u64 *d_pidx = c->alloc<u64>(np + 1), *d_pick = c->alloc<u64>(4 * (np + 1));
+        bfq_fastq_part_index(c, &fq, c->residentPstart, np, d_pidx);
+        std::vector<u64> hp(4 * (np + 1), 0);
+        bool pickF = false, pickH = false;
+        HIP_CHECK(hipMemcpyAsync(hp.data(), d_pidx, 8 * (np + 1), hipMemcpyDeviceToHost, c->stream));
+        bfq_pick_u64(c, fq.roff, d_pidx, np + 1, 1, d_pick + 2 * (np + 1));               // roff[i] + i
         if (J->out_hdr) {
             u8 *d_hdr = nullptr;
+            u64 *hOff = nullptr;
             u64 hl = 0;
-            bfq_fastq_hdr_stream(c, fq.N, c->d_text, &fq, &d_hdr, &hl, nullptr);
+            bfq_fastq_hdr_stream(c, fq.N, c->d_text, &fq, &d_hdr, &hl, &hOff);
             J->hdr_len = hl;
             if (hl > J->cap_hdr) throw BfqError{BFQ_E_ARG, "stream buffer too small"};
             bfq_download(c, J->out_hdr, d_hdr, hl);
+            bfq_pick_u64(c, hOff, d_pidx, np + 1, 0, d_pick + 3 * (np + 1));
+            pickH = true;
         }
         if (J->out_dna || J->out_qs) {
             if (sl > J->cap_stream) throw BfqError{BFQ_E_ARG, "stream buffer too small"};
@@ -208,14 +229,23 @@ extern "C" int bfq_glob_finish(bfq_ctx *c, uint8_t *d_dna, uint8_t *d_qs, bfq_fa
         }
         if (J->out_fastq) {
             u8 *d_out = nullptr;
-            u64 ol = bfq_fastq_format(c, d_dna, d_qs, fq.roff, fq.N, J->keep_headers ? 2 : 0, c->d_text, c->residentLen, &fq, &d_out, nullptr, true);
+            u64 *recOff = nullptr;
+            u64 ol = bfq_fastq_format(c, d_dna, d_qs, fq.roff, fq.N, J->keep_headers ? 2 : 0, c->d_text, c->residentLen, &fq, &d_out, &recOff, true);
             J->fastq_len = ol;
             if (ol > J->cap_fastq) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text"};
             bfq_download(c, J->out_fastq, d_out, ol);
+            bfq_pick_u64(c, recOff, d_pidx, np + 1, 0, d_pick + (np + 1));
+            pickF = true;
         }
+        HIP_CHECK(hipMemcpyAsync(hp.data() + (np + 1), d_pick + (np + 1), 8 * 3 * (np + 1), hipMemcpyDeviceToHost, c->stream));
         c->fetchCounters();
         c->profCollect();
         for (int p = 0; p <= BFQ_MAX_PARTS; p++) J->part_reads[p] = J->part_fastq_off[p] = J->part_stream_off[p] = J->part_hdr_off[p] = 0;
-        J->part_reads[1] = fq.N; J->part_fastq_off[1] = J->fastq_len; J->part_stream_off[1] = J->stream_len; J->part_hdr_off[1] = J->hdr_len;
+        for (int p = 0; p <= np; p++) {
+            J->part_reads[p] = hp[p];
+            J->part_fastq_off[p] = pickF ? hp[(np + 1) + p] : 0;
+            J->part_stream_off[p] = hp[2 * (np + 1) + p];
+            J->part_hdr_off[p] = pickH ? hp[3 * (np + 1) + p] : 0;
+        }
     });
 }

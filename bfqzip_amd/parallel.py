@@ -254,8 +254,9 @@ def deal_piles(counts, world):
 
 def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_streams=False, want_hdr=False, log=None):
     """ONE collection over all ranks with the result of the unsharded run (k_global.hip): every rank parses its share of the
-    file, the terminated text is exchanged, the two-symbol piles of the global eBWT are dealt to the ranks, the edits are
-    combined with one all-reduce, and every rank writes its own reads.  Single-end input."""
+    file(s), the terminated text is exchanged, the two-symbol piles of the global eBWT are dealt to the ranks, the edits are
+    combined with one all-reduce, and every rank writes its own reads.  Two input files (paired end) form ONE collection --
+    all reads of file 1, then all reads of file 2, as `BFQzip_parallel.py -p -t 0` appends them -- and give two outputs."""
     import time
     import torch
     dev = torch.device(eng.tensor_device)
@@ -267,28 +268,43 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
         if dev.type == "cuda":
             torch.cuda.synchronize()
         now = time.perf_counter(); tm[name] = round(tm.get(name, 0.0) + now - t_last[0], 4); t_last[0] = now
-    buf = map_file(inputs[0])
-    idx = TextIndex(buf, comm, host.text_line_counts, host.text_nth_newline)
-    if idx.num_lines % 4:
-        raise ValueError("FASTQ: number of lines is not a multiple of 4")
-    R, W, r = idx.num_lines // 4, comm.world, comm.rank
-    b0, b1 = idx.line_start(4 * (R * r // W)), idx.line_start(4 * (R * (r + 1) // W))
+    nf = len(inputs)
+    W, r = comm.world, comm.rank
+    bufs = [map_file(p) for p in inputs]
+    parts, tlen = [], 0
+    for buf in bufs:                                                 # my share of every file: reads R r / W .. R (r + 1) / W
+        idx = TextIndex(buf, comm, host.text_line_counts, host.text_nth_newline)
+        if idx.num_lines % 4:
+            raise ValueError("FASTQ: number of lines is not a multiple of 4")
+        R = idx.num_lines // 4
+        b0, b1 = idx.line_start(4 * (R * r // W)), idx.line_start(4 * (R * (r + 1) // W))
+        parts.append(buf[b0:b1]); tlen += b1 - b0
     lap("index")
-    N_loc, tot_loc = eng.glob_begin([buf[b0:b1]])
+    Np, Tp = eng.glob_begin(parts)                                    # reads / bases of each of my parts
     lap("upload+parse")
-    sz = comm.all_gather_i64(np.array([N_loc, tot_loc, b1 - b0], np.int64))
-    rows = sz[:, 0] + sz[:, 1]
-    base = np.concatenate([[0], np.cumsum(rows)]).astype(np.int64)
-    n = int(base[-1])
+    sz = comm.all_gather_i64(np.array([Np[f] + Tp[f] for f in range(nf)], np.int64))       # rows [rank][file]
+    # global text = file 0's parts in rank order, then file 1's: base[f][k] = first row of rank k's part of file f
+    flat = np.concatenate([[0], np.cumsum(sz.T.reshape(-1))]).astype(np.int64)
+    base = flat[:-1].reshape(nf, W)
+    n = int(flat[-1])
     t8 = torch.empty(max(n, 1), dtype=torch.uint8, device=dev); q8 = torch.empty_like(t8)
-    lo, hi = int(base[r]), int(base[r + 1])
-    if hi > lo:
-        eng.glob_local_text(t8[lo:hi], q8[lo:hi])
-    for src in range(W):                                             # every rank ends up with the whole text
-        comm.broadcast_(t8[int(base[src]):int(base[src + 1])], src)
-        comm.broadcast_(q8[int(base[src]):int(base[src + 1])], src)
+    myrows = [int(sz[r][f]) for f in range(nf)]
+    if sum(myrows):
+        lt = torch.empty(sum(myrows), dtype=torch.uint8, device=dev); lq = torch.empty_like(lt)
+        eng.glob_local_text(lt, lq)                                   # my parts back to back
+        o = 0
+        for f in range(nf):
+            t8[int(base[f][r]):int(base[f][r]) + myrows[f]] = lt[o:o + myrows[f]]
+            q8[int(base[f][r]):int(base[f][r]) + myrows[f]] = lq[o:o + myrows[f]]
+            o += myrows[f]
+        del lt, lq
+    for f in range(nf):                                               # every rank ends up with the whole text
+        for src in range(W):
+            lo, hi = int(base[f][src]), int(base[f][src]) + int(sz[src][f])
+            comm.broadcast_(t8[lo:hi], src)
+            comm.broadcast_(q8[lo:hi], src)
     lap("text exchange")
-    tot = {"blocks": 1, "reads": N_loc, "bases": tot_loc, "stats": {}, "seconds": tm}
+    tot = {"blocks": 1, "reads": sum(Np), "bases": sum(Tp), "stats": {}, "seconds": tm}
     sym = torch.empty_like(t8); qual = torch.empty_like(t8)
     if n:
         counts = eng.glob_pile_counts(t8, n)
@@ -306,28 +322,36 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
         lap("piles")
         sym ^= osym; qual ^= oqual                                   # what this rank's piles changed (zero elsewhere)
         comm.all_reduce_sum_(sym); comm.all_reduce_sum_(qual)
-        dna = osym[lo:hi] ^ sym[lo:hi]; qs = oqual[lo:hi] ^ qual[lo:hi]
+        segs = [(int(base[f][r]), int(base[f][r]) + myrows[f]) for f in range(nf)]
+        dna = torch.cat([osym[a:b] ^ sym[a:b] for a, b in segs]); qs = torch.cat([oqual[a:b] ^ qual[a:b] for a, b in segs])
         del sym, qual, osym, oqual
         lap("delta all-reduce")
     else:
         dna = torch.empty(0, dtype=torch.uint8, device=dev); qs = dna.clone()
-    res = eng.glob_finish(dna, qs, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr, text_len=int(b1 - b0))
-    # outputs at their final offsets: one block per rank, in rank order
+    res = eng.glob_finish(dna, qs, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr, text_len=int(tlen), nparts=nf)
+    # outputs at their final offsets: output f = the shares of part f of all ranks, in rank order
     kinds = [k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w]
     if comm.rank == 0:
-        for k in kinds:
-            open(names[0][k], "wb").close()
+        for f in range(nf):
+            for k in kinds:
+                open(names[f][k], "wb").close()
     comm.barrier()
     data = {"fastq": res.fastq, "dna": res.dna, "qs": res.qs, "hdr": res.hdr}
-    sizes = np.array([len(data[k]) if k in kinds else 0 for k in KINDS], np.int64)
-    allsz = comm.all_gather_i64(sizes)
+    cut = {"fastq": res.part_fastq_off, "dna": res.part_stream_off, "qs": res.part_stream_off, "hdr": res.part_hdr_off}
+    sizes = np.zeros((nf, 4), np.int64)
+    for f in range(nf):
+        for ki, kind in enumerate(KINDS):
+            if kind in kinds:
+                sizes[f, ki] = cut[kind][f + 1] - cut[kind][f]
+    allsz = comm.all_gather_i64(sizes.reshape(-1)).reshape(W, nf, 4)
     before = allsz[:comm.rank].sum(axis=0)
-    for ki, kind in enumerate(KINDS):
-        if kind in kinds:
-            fd = os.open(names[0][kind], os.O_WRONLY)
-            if sizes[ki]:
-                pwrite_all(fd, data[kind], int(before[ki]))
-            os.close(fd)
+    for f in range(nf):
+        for ki, kind in enumerate(KINDS):
+            if kind in kinds:
+                fd = os.open(names[f][kind], os.O_WRONLY)
+                if sizes[f, ki]:
+                    pwrite_all(fd, data[kind][cut[kind][f]:cut[kind][f + 1]], int(before[f, ki]))
+                os.close(fd)
     comm.barrier()
     lap("format+write")
     keys = sorted(tot["stats"]) if tot["stats"] else ["num_clust", "num_clust_discarded", "num_clust_amb_discarded", "num_clust_mod",
@@ -363,7 +387,7 @@ def main(argv=None):
     ap.add_argument("--streams-only", action="store_true", help="with --m2/--m3: do not write the merged FASTQ text")
     ap.add_argument("--pinned", action="store_true", help="page-locked output buffers (direct DMA)")
     ap.add_argument("--global", dest="glob", action="store_true",
-                    help="ONE eBWT over the whole input, its piles dealt to the GPUs: the result of the unsharded run (single-end; -t ignored)")
+                    help="ONE eBWT over the whole input, its piles dealt to the GPUs: the result of the unsharded run (-t is ignored)")
     ap.add_argument("--M", type=int, default=2); ap.add_argument("--B", type=int, default=0)
     a = ap.parse_args(argv)
     if a.paired and len(a.input) != 2:
@@ -401,10 +425,7 @@ def main(argv=None):
         bufs = {k: p.array for k, p in pins.items()}
     log = (lambda m: print(f"[rank {comm.rank}] {m}", flush=True)) if a.v else None
     if a.glob:
-        if a.paired:
-            print("=== ERROR ===\n--global takes one input file", file=sys.stderr)
-            return 1
-        tot = run_global(eng, comm, a.input, names, headers=a.headers, want_fastq=not (streams and a.streams_only),
+        tot = run_global(eng, comm, a.input[:2 if a.paired else 1], names, headers=a.headers, want_fastq=not (streams and a.streams_only),
                          want_streams=streams, want_hdr=a.m3, log=log)
     else:
         tot = run_files(eng, comm, a.input, a.threads, names, paired=a.paired, headers=a.headers,

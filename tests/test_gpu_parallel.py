@@ -135,3 +135,33 @@ def test_global_mode_gives_the_unsharded_result(tmp_path):
         nm = parallel.output_names([f], out, False)[0]
         for k in want:
             assert open(nm[k], "rb").read() == want[k], (world, k)
+
+
+def test_global_mode_paired(tmp_path):
+    """--global -p: two files = ONE collection (file 1's reads, then file 2's); the two outputs are the shares of the unsharded
+    paired run = one bfq_fastq_run_job over both files (what the reference's -p with a single block computes)."""
+    from bfqzip_amd import api, parallel, fastq
+    out = str(tmp_path / "G")
+    f1, f2 = paired_inputs(str(tmp_path))
+    g1, g2 = str(tmp_path / "s1.fastq"), str(tmp_path / "s2.fastq")
+    for path, seed in ((g1, 41), (g2, 42)):
+        b, q, r = api.synth_host(api.synth_spec(100_000, 40, Lmax=90, seed=seed, coverage=30, err_ppm=15000, snp_every=97, dsnp_every=131))
+        idx = np.arange(len(r) - 1)
+        h = fastq.HeaderSpans.from_list([x.encode() for x in np.char.add("@P%d." % seed, idx.astype(str)).tolist()])
+        open(path, "wb").write(fastq.format_fastq(b, q, r, h))
+    for (a, b), par, extra in (((f1, f2), dict(m=5), []), ((g1, g2), dict(m=5, M=3, B=1), ["--M", "3", "--B", "1"])):
+        eng = api.Engine(0, **par)
+        ref = eng.fastq_job([open(a, "rb").read(), open(b, "rb").read()], keep_headers=True, fastq=True, streams=True, hdr=True)
+        eng.close()
+        want = []
+        for o in range(2):
+            want.append({"fastq": ref.fastq[ref.part_fastq_off[o]:ref.part_fastq_off[o + 1]].tobytes(),
+                         "dna": ref.dna[ref.part_stream_off[o]:ref.part_stream_off[o + 1]].tobytes(),
+                         "qs": ref.qs[ref.part_stream_off[o]:ref.part_stream_off[o + 1]].tobytes(),
+                         "hdr": ref.hdr[ref.part_hdr_off[o]:ref.part_hdr_off[o + 1]].tobytes()})
+        for world in (1, 2):
+            _launch(world, [a, b, "-p", "-o", out, "--global", "--m3"] + extra, str(tmp_path))
+            names = parallel.output_names([a, b], out, True)
+            for o in range(2):
+                for k in want[o]:
+                    assert open(names[o][k], "rb").read() == want[o][k], (world, o, k)

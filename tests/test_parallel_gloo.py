@@ -112,6 +112,19 @@ def test_global_mode_equals_the_unsharded_run(orc, tmp_path):
     check_streams(names, [EXAMPLE])
 
 
+def test_global_mode_paired(orc, tmp_path):
+    """Two files = ONE collection (file 1's reads, then file 2's): the result of the unsharded paired run -- which is the
+    reference's `-p` with one block -- cut back into OUT_1 / OUT_2; single process and (below) 2 ranks."""
+    f1, f2 = paired_inputs(str(tmp_path))
+    ref = util.OracleEngine(orc, m=5).fastq_job([open(f1, "rb").read(), open(f2, "rb").read()], keep_headers=True)
+    want = (ref.fastq[:ref.part_fastq_off[1]].tobytes(), ref.fastq[ref.part_fastq_off[1]:].tobytes())
+    names = parallel.output_names([f1, f2], str(tmp_path / "G"), True)
+    parallel.run_global(util.OracleGlobalEngine(orc, m=5), parallel.Comm(), [f1, f2], names, headers=True, want_streams=True, want_hdr=True)
+    assert open(names[0]["fastq"], "rb").read() == want[0] and open(names[1]["fastq"], "rb").read() == want[1]
+    check_streams(names, [f1, f2])
+    assert _run2("global_paired", 2, str(tmp_path)) == hashlib.md5(want[0]).hexdigest() + hashlib.md5(want[1]).hexdigest()
+
+
 def _streams_of(fq_text, in_text):
     lines = fq_text.split(b"\n")[:-1]
     return (b"".join(x + b"\n" for x in lines[1::4]), b"".join(x + b"\n" for x in lines[3::4]),
@@ -144,6 +157,11 @@ def _worker(rank, world, port, mode, t, tmp, q):
             names = parallel.output_names([EXAMPLE], os.path.join(tmp, "G"), False)
             parallel.run_global(util.OracleGlobalEngine(orc, m=5), comm, [EXAMPLE], names)
             res = md5file(names[0]["fastq"])
+        elif mode == "global_paired":
+            f1, f2 = os.path.join(tmp, "r1.fastq"), os.path.join(tmp, "r2.fastq")
+            names = parallel.output_names([f1, f2], os.path.join(tmp, "G2"), True)
+            parallel.run_global(util.OracleGlobalEngine(orc, m=5), comm, [f1, f2], names, headers=True)
+            res = md5file(names[0]["fastq"]) + md5file(names[1]["fastq"])
         elif mode == "m3":
             names = parallel.output_names([EXAMPLE], os.path.join(tmp, "OUT"), False)
             parallel.run_files(eng, comm, [EXAMPLE], t, names, headers=True, want_streams=True, want_hdr=True)

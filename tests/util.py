@@ -172,12 +172,20 @@ class OracleGlobalEngine(OracleEngine):
 
     def glob_begin(self, parts):
         from bfqzip_amd import fastq as fqm
-        self.text = b"".join(bytes(np.asarray(p, np.uint8).tobytes()) for p in parts)
-        if self.text and not self.text.endswith(b"\n"):
-            self.text += b"\n"
+        texts = []
+        for p in parts:
+            t = bytes(np.asarray(p, np.uint8).tobytes())
+            if t and not t.endswith(b"\n"):
+                t += b"\n"
+            texts.append(t)
+        self.text = b"".join(texts)
         b, q, r, h = fqm.parse_fastq_bytes(self.text)
         self.blk = (b, q, r, h)
-        return len(r) - 1, int(r[-1])
+        self.pr = [0]
+        for t in texts:
+            self.pr.append(self.pr[-1] + t.count(b"\n") // 4)
+        return ([self.pr[i + 1] - self.pr[i] for i in range(len(texts))],
+                [int(r[self.pr[i + 1]]) - int(r[self.pr[i]]) for i in range(len(texts))])
 
     def glob_local_text(self, t8, q8):
         b, q, r, h = self.blk
@@ -236,7 +244,7 @@ class OracleGlobalEngine(OracleEngine):
         out["n_rows"] = int(cnt[s][s2])
         return out
 
-    def glob_finish(self, dna, qs, keep_headers=False, fastq=True, streams=False, hdr=False, text_len=0):
+    def glob_finish(self, dna, qs, keep_headers=False, fastq=True, streams=False, hdr=False, text_len=0, nparts=1):
         from bfqzip_amd import api, fastq as fqm
         b, q, r, h = self.blk
         d, s = dna.numpy().copy(), qs.numpy().copy()
@@ -259,6 +267,14 @@ class OracleGlobalEngine(OracleEngine):
         res.dna = d if streams else None
         res.qs = s if streams else None
         res.hdr = np.frombuffer(fqm.format_headers(h), np.uint8) if hdr else None
+        hl = h.lengths() if len(h) else np.zeros(0, np.int64)
+        Ls = np.diff(r.astype(np.int64))
+        fsz = np.concatenate([[0], np.cumsum((hl if keep_headers else np.ones(len(Ls), np.int64)) + 2 * Ls + 5)])
+        hsz = np.concatenate([[0], np.cumsum(hl + 1)])
+        res.part_reads = list(self.pr)
+        res.part_fastq_off = [int(fsz[i]) for i in self.pr]
+        res.part_stream_off = [int(r[i]) + i for i in self.pr]
+        res.part_hdr_off = [int(hsz[i]) for i in self.pr]
         res.stats = {}
         return res
 
