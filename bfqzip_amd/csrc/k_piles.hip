@@ -25,14 +25,19 @@ __global__ __launch_bounds__(256) void k_pile_count(const u8 *__restrict__ T8, u
         const u64 lo = b * (u64)PB, hi = (lo + PB < n) ? lo + PB : n;
         u32 c[6] = {0, 0, 0, 0, 0, 0};
         for (u64 p = lo + (u64)threadIdx.x * 16; p < hi; p += 256 * 16) {       // T8 is 16-byte aligned (and padded), PB a multiple of 16
-            if (first == 7u && p + 16 <= hi) {
+            if (p + 16 <= hi && p + 17 <= n + 64) {                    // 16 positions from one 16-byte load (T8 is padded by 64 bytes)
                 const uint4 x = *(const uint4 *)(T8 + p);
                 const u32 w[4] = {x.x, x.y, x.z, x.w};
+                const u32 after = (p + 16 < n) ? (u32)T8[p + 16] : 0u; // symbol that follows the 16th position
 #pragma unroll
                 for (int q = 0; q < 4; q++)
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        const u32 v = (w[q] >> (8 * k)) & 7u;
+                        u32 v = (w[q] >> (8 * k)) & 7u;
+                        if (first != 7u) {
+                            if (v != first) continue;
+                            v = (k < 3) ? (w[q] >> (8 * (k + 1))) & 7u : (q < 3 ? w[q + 1] & 7u : after & 7u);   // its second symbol
+                        }
 #pragma unroll
                         for (int s = 0; s < 6; s++) c[s] += (v == (u32)s);
                     }
