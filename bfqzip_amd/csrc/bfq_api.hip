@@ -46,6 +46,12 @@ void bfq_ctx::reserve(size_t bytes)
     wsTop = 0;
     d_bwt = d_qual = nullptr; d_lcp = nullptr; d_gcnt = nullptr; n = N = 0;
 }
+void bfq_ctx::dropWorkspace()
+{
+    HIP_CHECK(hipStreamSynchronize(stream));
+    if (ws) { HIP_CHECK(hipFree(ws)); ws = nullptr; wsCap = 0; wsTop = 0; }
+    d_bwt = d_qual = nullptr; d_lcp = nullptr; d_gcnt = nullptr;
+}
 void *bfq_ctx::allocBytes(size_t bytes)
 {
     size_t a = (wsTop + 255) & ~(size_t)255;
@@ -680,7 +686,7 @@ __global__ __launch_bounds__(256) void k_lcp_narrow(const u16 *__restrict__ lcp,
 }
 
 static void fastq_build_ebwt_core(bfq_ctx *c, TextSrc text, int term_out, HostRef bwt, HostRef qs, HostRef lcp, int lcp_bytes,
-                                  uint64_t cap_rows, uint64_t *n_rows, uint64_t *n_reads)
+                                  uint64_t cap_rows, uint64_t *n_rows, uint64_t *n_reads, bool earlyFree = false)
 {
     if (!lcp.null() && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
     std::vector<u64> ps;
@@ -693,6 +699,24 @@ static void fastq_build_ebwt_core(bfq_ctx *c, TextSrc text, int term_out, HostRe
     if (n_reads) *n_reads = fq.N;
     if (n > cap_rows) throw BfqError{BFQ_E_ARG, "output buffers smaller than the eBWT (need total bases + reads entries)"};
     bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, term_out, nullptr);
+    if (earlyFree && lcp.null() && 2 * (n + 256) <= c->textCap) {
+        // One-shot tools (the _fd entry points): the driver scrubs freed HBM at ~28 GB/s and the NEXT process's first
+        // allocation waits for it (profiles/microbench/alloc_after_exit.hip: 4-6 s behind a process that held 120 GiB).
+        // The eBWT and its qualities move into the text buffer (the text is dead), the workspace is freed now, and the
+        // scrubbing runs while the outputs are still being written.
+        c->fetchCounters();
+        check_counters(c);
+        u8 *keepB = c->d_text, *keepQ = c->d_text + ((n + 255) & ~255ull);
+        HIP_CHECK(hipMemcpyAsync(keepB, c->d_bwt, n, hipMemcpyDeviceToDevice, c->stream));
+        HIP_CHECK(hipMemcpyAsync(keepQ, c->d_qual, n, hipMemcpyDeviceToDevice, c->stream));
+        c->sync();
+        c->profCollect();
+        c->dropWorkspace();
+        if (!bwt.null()) bfq_download(c, bwt, keepB, n);
+        if (!qs.null()) bfq_download(c, qs, keepQ, n);
+        c->sync();
+        return;
+    }
     if (!bwt.null()) bfq_download(c, bwt, c->d_bwt, n);
     if (!qs.null()) bfq_download(c, qs, c->d_qual, n);
     if (!lcp.null()) {
@@ -725,7 +749,7 @@ extern "C" int bfq_fastq_build_ebwt_fd(bfq_ctx *c, int fastq_fd, uint64_t len, i
         if (fastq_fd < 0) throw BfqError{BFQ_E_ARG, "bad file descriptor"};
         fastq_build_ebwt_core(c, TextSrc{HostRef::file(fastq_fd), len}, term_out, bwt_fd >= 0 ? HostRef::file(bwt_fd) : HostRef(),
                               bwtqs_fd >= 0 ? HostRef::file(bwtqs_fd) : HostRef(), lcp_fd >= 0 ? HostRef::file(lcp_fd) : HostRef(), lcp_bytes,
-                              ~0ull, n_rows, n_reads);
+                              ~0ull, n_rows, n_reads, true);
     });
 }
 

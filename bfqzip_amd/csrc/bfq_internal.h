@@ -69,6 +69,7 @@ struct bfq_ctx {
     char *ws = nullptr;
     size_t wsCap = 0, wsTop = 0;
     void reserve(size_t bytes);
+    void dropWorkspace();           // frees the arena now (one-shot tools: lets the driver scrub it while outputs are written)
     void *allocBytes(size_t bytes);
     template <class T> T *alloc(size_t count) { return (T *)allocBytes(count * sizeof(T)); }
     size_t mark() const { return wsTop; }
