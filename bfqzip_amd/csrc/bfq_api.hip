@@ -313,11 +313,12 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     A.w0 = c->alloc<u32>(n + 16);
     size_t mB = c->mark();
     B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16);
-    u8 *T8 = (u8 *)B.w0, *Q8 = (u8 *)B.w12;             // dead before the sort's first scatter
+    u8 *T8 = (u8 *)A.w0, *Q8 = (u8 *)A.w12;             // dead before the sort's first scatter
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
     u32 *hist0 = c->alloc<u32>(256 * ceil_div(n, BFQ_RS_BLOCK_ELEMS));
-    bfq_build_keys(c, T8, Q8, text3, n, A, hist0);
-    bfq_radix_sort(c, A, B, n, 6, hist0);
+    bfq_build_keys(c, T8, Q8, text3, n, B, hist0);      // the records start in B: five passes later they are in A
+    static_assert(BFQ_KEY_PASSES & 1, "an odd number of passes ends in the other buffer");
+    bfq_radix_sort(c, B, A, n, BFQ_KEY_PASSES, hist0);
     c->release(mB);                                     // the big-segment list reuses the B buffers
     bfq_refine(c, A, text3, n, c->d_lcp, st);
     bfq_emit_bwt(c, A, n, termOut, c->d_bwt, c->d_qual, c->d_gcnt);

@@ -96,16 +96,36 @@ BFQ_HD u64 bfq_window(const u64 *text3, u64 p)
 }
 BFQ_HD u64 bfq_key_at(const u64 *text3, u64 p) { return bfq_mask_key(bfq_window(text3, p)); }
 
-// ---- sort record of one suffix: three 32-bit words kept in three arrays (12 bytes per row)
-//   key48   = the suffix's first 16 symbols (top 48 bits of the masked 63-bit window)
+// ---- sort record of one suffix: three 32-bit words (12 bytes per row), w0 in one array, (w1, w2) in another
+//   skey    = the suffix's first 16 symbols as key40 | L << 40
+//             key40: two symbols (c0, c1) -> one 5-bit group, 0 for "#", else 6*c0 + c1 - 5 (1..30).  After a terminator
+//             every symbol is 0, so the map is one-to-one and keeps the order: 8 groups = 40 bits = five 8-bit radix
+//             digits instead of the six a 3-bit-per-symbol key needs.
+//             L: symbols before the first terminator among the 16 (16: none) -- a function of key40, carried along
+//             so that "complete suffix" and the common prefix of equal keys need no decoding.
 //   payload = text position (37 bits) | preceding symbol code << 37 | its quality << 40   (48 bits)
-//   w0 = key48 >> 16 ;  w1 = (key48 & 0xFFFF) << 16 | payload >> 32 ;  w2 = payload & 0xFFFFFFFF
-// 8-bit radix digits of key48: digits 0,1 live in w1 (bits 16..31), digits 2..5 in w0.
+//   w0 = key40 >> 8 ;  w1 = (key40 & 0xFF) << 24 | L << 16 | payload >> 32 ;  w2 = payload & 0xFFFFFFFF
+// 8-bit radix digits of key40: digit 0 lives in w1 (bits 24..31), digits 1..4 in w0.
 #define BFQ_KEY_SYMS 16
+#define BFQ_KEY_PASSES 5
 #define BFQ_POS_BITS 37
 #define BFQ_POS_MASK ((1ull << BFQ_POS_BITS) - 1ull)
-#define BFQ_LOW3_48 0x0000249249249249ull   // bit 0 of each of the 16 fields of a key48
-BFQ_HD u64 bfq_key48_of(u64 maskedKey63) { return maskedKey63 >> 15; }
+BFQ_HD u64 bfq_key40_of_key48(u64 X)                 // X: 16 fields of 3 bits, first symbol on top, zero after a terminator
+{
+    const u64 M7 = 0x1C71C71C71C7ull, L1 = 0x041041041041ull;
+    u64 A = (X >> 3) & M7, B = X & M7;               // c0 / c1 of the 8 pairs, one pair per 6-bit lane
+    u64 S = (A << 2) + (A << 1) + B;                 // 6*c0 + c1 (<= 35: stays inside the lane)
+    u64 nz = (A | (A >> 1) | (A >> 2)) & L1;
+    S -= (nz << 2) + nz;                             // - 5 where c0 != 0
+    u64 v = (S & 0x03F03F03F03Full) | ((S & 0xFC0FC0FC0FC0ull) >> 1);      // 8 x 6 -> 4 x 10 -> 2 x 20 -> 40 bits
+    v = (v & 0x000FFF000FFFull) | ((v & 0xFFF000FFF000ull) >> 2);
+    return (v & 0xFFFFFull) | ((v >> 24) << 20);
+}
+BFQ_HD u64 bfq_skey_of(u64 maskedKey63)
+{
+    int t = bfq_key_tpos(maskedKey63);
+    return bfq_key40_of_key48(maskedKey63 >> 15) | ((u64)(t < BFQ_KEY_SYMS ? t : BFQ_KEY_SYMS) << 40);
+}
 BFQ_HD u64 bfq_pack_val(u64 pos, u32 prevCode, u32 prevQual)
 {
     return pos | ((u64)prevCode << 37) | ((u64)(prevQual & 0xFFu) << 40);
@@ -113,24 +133,24 @@ BFQ_HD u64 bfq_pack_val(u64 pos, u32 prevCode, u32 prevQual)
 BFQ_HD u64 bfq_val_pos(u64 v) { return v & BFQ_POS_MASK; }
 BFQ_HD u32 bfq_val_code(u64 v) { return (u32)(v >> 37) & 7u; }
 BFQ_HD u32 bfq_val_qual(u64 v) { return (u32)(v >> 40) & 0xFFu; }
-BFQ_HD u32 bfq_rec_w0(u64 key48) { return (u32)(key48 >> 16); }
-BFQ_HD u32 bfq_rec_w1(u64 key48, u64 pay) { return ((u32)(key48 & 0xFFFFu) << 16) | (u32)(pay >> 32); }
+// (any integer below 2^40 can stand in for an skey: the segment-id sorts of k_bigseg.hip)
+BFQ_HD u32 bfq_rec_w0(u64 skey) { return (u32)(skey >> 8); }
+BFQ_HD u32 bfq_rec_w1(u64 skey, u64 pay) { return ((u32)(skey & 0xFFu) << 24) | (((u32)(skey >> 40) & 31u) << 16) | (u32)(pay >> 32); }
 BFQ_HD u32 bfq_rec_w2(u64 pay) { return (u32)pay; }
-BFQ_HD u64 bfq_rec_key48(u32 w0, u32 w1) { return ((u64)w0 << 16) | (u64)(w1 >> 16); }
+BFQ_HD u64 bfq_rec_skey(u32 w0, u32 w1) { return ((u64)w0 << 8) | (u64)(w1 >> 24) | ((u64)((w1 >> 16) & 31u) << 40); }
 BFQ_HD u64 bfq_rec_pay(u32 w1, u32 w2) { return ((u64)(w1 & 0xFFFFu) << 32) | (u64)w2; }
-// key48 holds a terminator among its 16 symbols = it is a complete suffix
-BFQ_HD u64 bfq_key48_zero_fields(u64 k) { return ~(k | (k >> 1) | (k >> 2)) & BFQ_LOW3_48; }
-BFQ_HD bool bfq_key48_has_term(u64 k) { return bfq_key48_zero_fields(k) != 0; }
-// common prefix (symbols) of two key48; terminators never match
-BFQ_HD int bfq_key48_lcp(u64 a, u64 b)
+// the key holds a terminator among its 16 symbols = it is a complete suffix
+BFQ_HD bool bfq_skey_has_term(u64 k) { return (u32)(k >> 40) < (u32)BFQ_KEY_SYMS; }
+// common prefix (symbols) of two skeys; terminators never match
+BFQ_HD int bfq_skey_lcp(u64 a, u64 b)
 {
-    u64 x = a ^ b;
-    if (x == 0) {
-        u64 z = bfq_key48_zero_fields(a);
-        if (z == 0) return BFQ_KEY_SYMS;
-        return (45 - (63 - bfq_clz64(z))) / 3;
-    }
-    return (bfq_clz64(x) - 16) / 3;
+    u64 x = (a ^ b) & 0xFFFFFFFFFFull;
+    if (x == 0) return (int)(a >> 40);
+    int gi = ((bfq_clz64(x) - 24) * 13) >> 6;        // first group that differs (/5 for 0..39)
+    int sh = 35 - 5 * gi;
+    u32 ga = (u32)(a >> sh) & 31u, gb = (u32)(b >> sh) & 31u;
+    u32 ca = ((ga + 5u) * 43u) >> 8, cb = ((gb + 5u) * 43u) >> 8;   // the group's first symbol: (g + 5) / 6
+    return 2 * gi + (ca == cb ? 1 : 0);
 }
 
 // ---- Illumina 8-level binning, ASCII in/out (bfq_int.cpp:307-319) ------------

@@ -170,7 +170,7 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
 #define BFQ_RS_BLOCK_ELEMS 98304
 void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0);   // hist0: [256][ceil(n / BFQ_RS_BLOCK_ELEMS)]
 // LSD radix sort of the records on their 48-bit key; result ends in A
-void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes = 6, const u32 *hist0 = nullptr);   // passes even; fewer = low digits only; hist0: pass-0 counts already made
+SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes = BFQ_KEY_PASSES, const u32 *hist0 = nullptr);   // returns the buffer holding the result (in: even passes, tmp: odd); fewer passes = low digits only; hist0: pass-0 counts already made
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
 void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
 // segments above BFQ_HUGE_SEG rows (listed by k_refine_big): whole-device radix rounds on the following symbols

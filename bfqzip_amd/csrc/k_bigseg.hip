@@ -4,8 +4,8 @@
 //
 // The rows of all such segments of a batch are laid out as "slots" (slot j <-> a fixed eBWT row,
 // segments back to back).  One round looks at the next 16 symbols of every slot's suffix:
-//   k_huge_keys    : key48 of the suffix at depth d, record (key48, slot)
-//   radix sort     : by key48 (the 6-pass LSD sort of step 1, stable)
+//   k_huge_keys    : sort key of the suffix at depth d, record (key, slot)
+//   radix sort     : by key (the 5-pass LSD sort of step 1, stable)
 //   k_huge_segkeys : record (sub-segment id, slot) in that order; radix sort (4 passes, stable)
 //                    -> grouped by sub-segment, ordered by key, ties in the previous order
 //   k_huge_apply   : payloads / keys gathered into the new slot order
@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k_huge_keys(const u64 *__restrict__ pay, 
 {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
-        u64 k = bfq_key48_of(bfq_key_at(text3, bfq_val_pos(pay[j]) + depth));
+        u64 k = bfq_skey_of(bfq_key_at(text3, bfq_val_pos(pay[j]) + depth));
         K[j] = k;
         R.w0[j] = bfq_rec_w0(k);
         R.w12[j] = ((u64)bfq_rec_w2(j) << 32) | bfq_rec_w1(k, j);
@@ -80,14 +80,14 @@ __global__ __launch_bounds__(256) void k_huge_bounds(const u64 *__restrict__ npa
     for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
         const u64 k = nK[j];
         const u32 sg = gseg[j];
-        const bool term = bfq_key48_has_term(k);
+        const bool term = bfq_skey_has_term(k);
         const bool first = (j == 0) || gseg[j - 1] != sg;
         const u64 kp = first ? 0ull : nK[j - 1];
         const bool head = first || kp != k || term;
         const bool nextTied = (j + 1 < m) && gseg[j + 1] == sg && nK[j + 1] == k && !term;
         const u64 r = grow[j];
         rec_set_pay(rec, r, npay[j]);
-        if (!first && head) lcp[r] = (u16)(depth + (u32)bfq_key48_lcp(kp, k));
+        if (!first && head) lcp[r] = (u16)(depth + (u32)bfq_skey_lcp(kp, k));
         const bool c = !head || nextTied;
         cont[j] = c ? 1 : 0;
         rhead[j] = (c && head) ? 1 : 0;
@@ -139,10 +139,11 @@ static void huge_batch(bfq_ctx *c, SortRec rec, const u64 *text3, u16 *lcp, cons
     for (u32 depth = BFQ_KEY_SYMS; m > 0; depth += BFQ_KEY_SYMS) {
         const unsigned g = bfq_grid(m, 256);
         KLAUNCH(c, K_HUGE_ROUND, 36.0 * (double)m, k_huge_keys, g, 256, (const u64 *)b.pay, text3, m, depth, b.K, b.R1);
-        bfq_radix_sort(c, b.R1, b.R2, m);
-        KLAUNCH(c, K_HUGE_ROUND, 28.0 * (double)m, k_huge_segkeys, g, 256, b.R1, (const u32 *)b.gseg, m, b.R2);
-        bfq_radix_sort(c, b.R2, b.R1, m, nsub <= (1ull << 16) ? 2 : 4);       // ids below 2^16: the two low digits are enough
-        KLAUNCH(c, K_HUGE_ROUND, 44.0 * (double)m, k_huge_apply, g, 256, b.R2, (const u64 *)b.pay, (const u64 *)b.K, m, b.npay, b.nK);
+        const SortRec S1 = bfq_radix_sort(c, b.R1, b.R2, m);                  // five passes: the result is in R2
+        const SortRec T1 = (S1.w0 == b.R1.w0) ? b.R2 : b.R1;
+        KLAUNCH(c, K_HUGE_ROUND, 28.0 * (double)m, k_huge_segkeys, g, 256, S1, (const u32 *)b.gseg, m, T1);
+        const SortRec S2 = bfq_radix_sort(c, T1, S1, m, nsub <= (1ull << 16) ? 2 : 4);   // ids below 2^16: the two low digits are enough
+        KLAUNCH(c, K_HUGE_ROUND, 44.0 * (double)m, k_huge_apply, g, 256, S2, (const u64 *)b.pay, (const u64 *)b.K, m, b.npay, b.nK);
         KLAUNCH(c, K_HUGE_ROUND, 44.0 * (double)m, k_huge_bounds, g, 256, (const u64 *)b.npay, (const u64 *)b.nK, (const u32 *)b.gseg,
                 (const u64 *)b.grow, m, depth, rec, lcp, b.cont, b.rhead);
         bfq_exscan_u8(c, b.cont, b.cpos, m, b.tot);

@@ -107,12 +107,12 @@ __global__ __launch_bounds__(256) void k_build_keys_pile(const u8 *__restrict__ 
                         const u32 o3 = o * 3u;
                         const u64 hi = (a << o3) & BFQ_M63;
                         const u64 lo = o3 ? (bnext >> (63u - o3)) : 0ull;
-                        const u64 k48 = bfq_key48_of(bfq_mask_key(hi | lo));
+                        const u64 sk = bfq_skey_of(bfq_mask_key(hi | lo));
                         const u32 pc = (cm >> (8 * k)) & 0xFFu;
                         const u32 pq = pc ? (q4 >> (8 * k)) & 0xFFu : (u32)'#';
                         const u64 pay = bfq_pack_val(p0 + k, pc, pq);
-                        out.w0[d] = bfq_rec_w0(k48);
-                        out.w12[d] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(k48, pay);
+                        out.w0[d] = bfq_rec_w0(sk);
+                        out.w12[d] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(sk, pay);
                         d++;
                     }
                     if (++o == BFQ_SYMS_PER_WORD) { o = 0; wd++; }
@@ -200,8 +200,8 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
         const size_t mB = c->mark();
         B.w0 = c->alloc<u32>(m + 16); B.w12 = c->alloc<u64>(m + 16);
         KLAUNCH(c, K_KEYS, 1.3 * (double)n + 12.0 * (double)m, k_build_keys_pile, bfq_grid(nb, 1), 256, (const u8 *)T8, (const u8 *)Q8,
-                (const u64 *)text3, n, s, s2, off, A, nb);
-        bfq_radix_sort(c, A, B, m, 6, nullptr);
+                (const u64 *)text3, n, s, s2, off, B, nb);
+        bfq_radix_sort(c, B, A, m);                               // five passes: B -> A
         c->release(mB);
         hipLaunchKernelGGL(k_refine_reset, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
         bfq_refine(c, A, text3, m, c->d_lcp + start, st);
@@ -271,8 +271,8 @@ u64 bfq_run_one_pile(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u
     A.w0 = c->alloc<u32>(m + 16);
     const size_t mB = c->mark();
     B.w0 = c->alloc<u32>(m + 16); B.w12 = c->alloc<u64>(m + 16);
-    KLAUNCH(c, K_KEYS, 1.3 * (double)n + 12.0 * (double)m, k_build_keys_pile, bfq_grid(nb, 1), 256, T8, Q8, text3, n, s, s2, (const u64 *)blkOff, A, nb);
-    bfq_radix_sort(c, A, B, m, 6, nullptr);
+    KLAUNCH(c, K_KEYS, 1.3 * (double)n + 12.0 * (double)m, k_build_keys_pile, bfq_grid(nb, 1), 256, T8, Q8, text3, n, s, s2, (const u64 *)blkOff, B, nb);
+    bfq_radix_sort(c, B, A, m);                                   // five passes: B -> A
     c->release(mB);
     hipLaunchKernelGGL(k_refine_reset, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
     bfq_refine(c, A, text3, m, out->lcp, nullptr);

@@ -1,5 +1,5 @@
-// k_radix.hip -- stable LSD radix sort of the suffix records on their 48-bit key (the first 16
-// symbols), 8-bit digits, 6 passes.
+// k_radix.hip -- stable LSD radix sort of the suffix records on their 40-bit key (the first 16
+// symbols, two per 5-bit group: bfq_common.h), 8-bit digits, 5 passes.
 //
 // This is the sort at the heart of the eBWT construction that replaces
 // `gsufsort --bwt --qs` (call site BFQzip.py:184): one record per read suffix.  A record is
@@ -89,6 +89,20 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
         // tile order = (wave, round, lane): wave w owns slots [w*1024, w*1024+1024)
         u32 a0[RS_ROUNDS], a1[RS_ROUNDS], a2[RS_ROUNDS];
         u32 pk[RS_ROUNDS];                                       // digit << 16 | rank, later digit << 16 | tile slot
+        if (DW) {                                                // the digit word first: the ranking starts on it
+#pragma unroll
+            for (int r = 0; r < RS_ROUNDS; r++) {
+                u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
+                u64 x12 = slot < cnt ? in.w12[tbase + slot] : 0xFFFFFFFFull;
+                a1[r] = (u32)x12;
+                a2[r] = (u32)(x12 >> 32);
+            }
+#pragma unroll
+            for (int r = 0; r < RS_ROUNDS; r++) {
+                u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
+                a0[r] = slot < cnt ? in.w0[tbase + slot] : 0xFFFFFFFFu;
+            }
+        } else
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
             u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
@@ -166,18 +180,25 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
     }
 }
 
-// key48 digits: 0,1 in w1 (bits 16..31), 2..5 in w0.  6 passes (even): the result returns to A.
-void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes, const u32 *hist0)
+// skey digits: 0 in w1 (bits 24..31), 1..4 in w0.  The records start in `in`; `tmp` is the other ping-pong buffer.
+// Returns the buffer that holds the result: `in` for an even number of passes, `tmp` for an odd one.
+SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes, const u32 *hist0)
 {
-    if (n < 2) return;
+    if (n < 2) {
+        if (n == 1 && (passes & 1)) {
+            HIP_CHECK(hipMemcpyAsync(tmp.w0, in.w0, 4, hipMemcpyDeviceToDevice, c->stream));
+            HIP_CHECK(hipMemcpyAsync(tmp.w12, in.w12, 8, hipMemcpyDeviceToDevice, c->stream));
+        }
+        return (passes & 1) ? tmp : in;
+    }
     u64 nb = ceil_div(n, RS_BLOCK_ELEMS);
     size_t m = c->mark();
     u32 *hist = c->alloc<u32>(256 * nb);
     u64 *off = c->alloc<u64>(256 * nb);
-    SortRec in = A, out = B;
+    SortRec out = tmp;
     for (int pass = 0; pass < passes; pass++) {
-        const int dw = pass < 2 ? 1 : 0;
-        const int shift = pass < 2 ? 16 + 8 * pass : 8 * (pass - 2);
+        const int dw = pass == 0 ? 1 : 0;
+        const int shift = pass == 0 ? 24 : 8 * (pass - 1);
         const bool have = (pass == 0 && hist0);            // pass 0's counts were made by k_build_keys
         if (!have && dw)
             KLAUNCH(c, K_RADIX_HIST, 8.0 * (double)n, k_radix_hist<u64>, nb, RS_THREADS, (const u64 *)in.w12, n, shift, hist, nb);
@@ -191,4 +212,5 @@ void bfq_radix_sort(bfq_ctx *c, SortRec A, SortRec B, u64 n, int passes, const u
         SortRec t = in; in = out; out = t;
     }
     c->release(m);
+    return in;
 }

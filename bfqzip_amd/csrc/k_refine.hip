@@ -88,8 +88,8 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
             } else if (r0 + 4 <= n) {
                 uint4 a = *(const uint4 *)(rec.w0 + r0);
                 uint4 b0 = *(const uint4 *)(rec.w12 + r0), b1 = *(const uint4 *)(rec.w12 + r0 + 2);
-                k[0] = bfq_rec_key48(a.x, b0.x); k[1] = bfq_rec_key48(a.y, b0.z);
-                k[2] = bfq_rec_key48(a.z, b1.x); k[3] = bfq_rec_key48(a.w, b1.z);
+                k[0] = bfq_rec_skey(a.x, b0.x); k[1] = bfq_rec_skey(a.y, b0.z);
+                k[2] = bfq_rec_skey(a.z, b1.x); k[3] = bfq_rec_skey(a.w, b1.z);
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; i++) k[i] = (r0 + i < n) ? rec_key(rec, r0 + i) : 0ull;
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                 bool h = true;                                 // rows past the end close the last segment
                 if (r < n) {
                     h = (r == 0) || seg_head(kp, k[i]);
-                    if (h && li0 + i < RF_CHUNK) lcp[r] = r ? (u16)bfq_key48_lcp(kp, k[i]) : (u16)0;
+                    if (h && li0 + i < RF_CHUNK) lcp[r] = r ? (u16)bfq_skey_lcp(kp, k[i]) : (u16)0;
                 }
                 nib |= (h ? 1u : 0u) << i;
                 kp = k[i];

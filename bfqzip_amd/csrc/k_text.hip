@@ -119,13 +119,13 @@ __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, c
                 u32 o3 = o * 3u;
                 u64 hi = (a << o3) & BFQ_M63;
                 u64 lo = o3 ? (bnext >> (63u - o3)) : 0ull;
-                u64 k48 = bfq_key48_of(bfq_mask_key(hi | lo));
+                u64 sk = bfq_skey_of(bfq_mask_key(hi | lo));
                 u32 pc = (c4 >> (8 * k)) & 0xFFu;
                 u32 pq = pc ? (q4 >> (8 * k)) & 0xFFu : (u32)'#';
                 u64 pay = bfq_pack_val(p0 + k, pc, pq);
-                rw0[k] = bfq_rec_w0(k48);
-                rw12[k] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(k48, pay);
-                if (p0 + k < n) atomicAdd(&wh[w][(u32)k48 & 255u], 1u);   // digit 0 of the LSD sort = low byte of the key
+                rw0[k] = bfq_rec_w0(sk);
+                rw12[k] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(sk, pay);
+                if (p0 + k < n) atomicAdd(&wh[w][(u32)sk & 255u], 1u);   // digit 0 of the LSD sort = low byte of the key
                 if (++o == BFQ_SYMS_PER_WORD) { o = 0; wd++; }
             }
             if (p0 + 4 <= n) {

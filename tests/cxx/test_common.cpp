@@ -1,5 +1,5 @@
 // Host-side unit test of bfq_common.h (the helpers the kernels share with the host):
-// key windows over the 3-bit packed text, terminator masking, LCP of keys, sort-record packing,
+// key windows over the 3-bit packed text, terminator masking, LCP of keys, the 40-bit sort key, sort-record packing,
 // Illumina binning.  Compared against byte-wise definitions.  Exit code 0 = all good.
 #include <cstdio>
 #include <cstdlib>
@@ -41,12 +41,14 @@ int main()
         CHECK(bfq_key_has_term(key) == (tpos < BFQ_SYMS_PER_WORD));
         CHECK(bfq_key_tpos(key) == tpos);
         CHECK((key >> 63) == 0);
-        // key48 = first 16 symbols
-        u64 k48 = bfq_key48_of(key);
-        CHECK(bfq_key48_has_term(k48) == (tpos < BFQ_KEY_SYMS));
+        // sort key = first 16 symbols in 40 bits + the terminator's place
+        u64 sk = bfq_skey_of(key);
+        CHECK((sk >> 45) == 0);
+        CHECK(bfq_skey_has_term(sk) == (tpos < BFQ_KEY_SYMS));
+        CHECK((int)(sk >> 40) == (tpos < BFQ_KEY_SYMS ? tpos : BFQ_KEY_SYMS));
         u64 pay = bfq_pack_val(p, p ? T[p - 1] : 0, 33 + (u32)(p % 90));
-        u32 w0 = bfq_rec_w0(k48), w1 = bfq_rec_w1(k48, pay), w2 = bfq_rec_w2(pay);
-        CHECK(bfq_rec_key48(w0, w1) == k48);
+        u32 w0 = bfq_rec_w0(sk), w1 = bfq_rec_w1(sk, pay), w2 = bfq_rec_w2(pay);
+        CHECK(bfq_rec_skey(w0, w1) == sk);
         CHECK(bfq_rec_pay(w1, w2) == pay);
         CHECK(bfq_val_pos(pay) == p && bfq_val_code(pay) == (p ? T[p - 1] : 0u) && bfq_val_qual(pay) == 33 + (u32)(p % 90));
     }
@@ -58,7 +60,12 @@ int main()
         while (l < BFQ_SYMS_PER_WORD && T[p + l] && p + l < n && q + l < n && T[p + l] == T[q + l]) l++;
         CHECK(bfq_key_lcp(a, b) == l);
         int l16 = l < BFQ_KEY_SYMS ? l : BFQ_KEY_SYMS;
-        CHECK(bfq_key48_lcp(bfq_key48_of(a), bfq_key48_of(b)) == l16);
+        const u64 sa = bfq_skey_of(a), sb = bfq_skey_of(b);
+        CHECK(bfq_skey_lcp(sa, sb) == l16);
+        // the 40-bit key keeps the order and the equality of the first 16 symbols (key >> 15: 3 bits per symbol)
+        const u64 ka = a >> 15, kb = b >> 15, M40 = (1ull << 40) - 1ull;
+        CHECK((ka < kb) == ((sa & M40) < (sb & M40)));
+        CHECK((ka == kb) == (sa == sb));
         // lexicographic order of the first 21 symbols (# smallest)
         int c = 0;
         for (int j = 0; j < BFQ_SYMS_PER_WORD && !c; j++) {
@@ -67,6 +74,21 @@ int main()
             if (x == 0 || y == 0) break;
         }
         CHECK((a < b) == (c < 0) || c == 0);
+    }
+    // pairs of 21-symbol windows with a chosen common prefix (random text rarely shares more than a few symbols)
+    for (int it = 0; it < 200000; it++) {
+        int sa_[21], sb_[21];
+        const int share = rnd() % 22, la = rnd() % 22, lb = rnd() % 22;       // la / lb: place of the terminator (21: none)
+        for (int j = 0; j < 21; j++) { sa_[j] = 1 + rnd() % 5; sb_[j] = (j < share) ? sa_[j] : 1 + rnd() % 5; }
+        u64 a = 0, b = 0;
+        for (int j = 0; j < 21; j++) { a = (a << 3) | (u64)(j < la ? sa_[j] : 0); b = (b << 3) | (u64)(j < lb ? sb_[j] : 0); }
+        int l = 0;
+        while (l < 16 && l < la && l < lb && sa_[l] == sb_[l]) l++;
+        const u64 ka = a >> 15, kb = b >> 15, M40 = (1ull << 40) - 1ull;
+        const u64 sa = bfq_skey_of(a), sb = bfq_skey_of(b);
+        CHECK(bfq_skey_lcp(sa, sb) == l);
+        CHECK((ka < kb) == ((sa & M40) < (sb & M40)));
+        CHECK((ka == kb) == (sa == sb));
     }
     for (int q = 0; q < 128; q++) {   // bfq_int.cpp:307-319
         int v = q - 33, e = v;
