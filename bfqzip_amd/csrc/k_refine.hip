@@ -200,17 +200,20 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                     // + #(earlier rows with a pair <= its own).  Only the first kind is compared
                     // (the pair of lane+d arrives by one-lane DPP shifts per step); the ballot of those
                     // comparisons, read at lane-d, gives the second kind by complement.
-                    int c = 0, inv = 0;
+                    // Which lanes take part is wave-uniform: lane l and lane l+d share a sub-segment iff lanes l+1 .. l+d are
+                    // no heads (scalar mask arithmetic); per step the vector unit only shifts, compares and counts.
+                    int c = (int)lane - sublo;                                       // (rows before me in my sub-segment) - inv + (later rows before me)
                     u64 U1 = W1, U2 = W2;
+                    u64 same = ~0ull;
+                    const u64 nh = ~curHeads;
                     for (u32 d = 1; d < maxsz; d++) {
+                        same &= nh >> d;
                         U1 = bfq_from_next_lane(U1);
                         U2 = bfq_from_next_lane(U2);
-                        bool f = un && ((int)lane + (int)d < subhi) && (U1 < W1 || (U1 == W1 && U2 < W2));   // row lane+d sorts before me
-                        u64 fb = __ballot(f);
-                        c += f ? 1 : 0;
-                        if (lane >= d) inv += (int)((fb >> (lane - d)) & 1ull);      // I sort before row lane-d
+                        const u64 fb = __builtin_amdgcn_ballot_w64(U1 < W1 || (U1 == W1 && U2 < W2)) & same;   // bit l: row l+d sorts before row l
+                        c += __builtin_amdgcn_inverse_ballot_w64(fb) ? 1 : 0;
+                        c -= __builtin_amdgcn_inverse_ballot_w64(fb << d) ? 1 : 0;            // I sort before row lane-d
                     }
-                    c += ((int)lane - sublo) - inv;
                     int np = un ? sublo + c : (int)lane;
                     v = bfq_permute64(v, np);
                     W1 = bfq_permute64(W1, np);
