@@ -89,28 +89,22 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
         // tile order = (wave, round, lane): wave w owns slots [w*1024, w*1024+1024)
         u32 a0[RS_ROUNDS], a1[RS_ROUNDS], a2[RS_ROUNDS];
         u32 pk[RS_ROUNDS];                                       // digit << 16 | rank, later digit << 16 | tile slot
-        if (DW) {                                                // the digit word first: the ranking starts on it
-#pragma unroll
-            for (int r = 0; r < RS_ROUNDS; r++) {
-                u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
-                u64 x12 = slot < cnt ? in.w12[tbase + slot] : 0xFFFFFFFFull;
-                a1[r] = (u32)x12;
-                a2[r] = (u32)(x12 >> 32);
-            }
-#pragma unroll
-            for (int r = 0; r < RS_ROUNDS; r++) {
-                u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
-                a0[r] = slot < cnt ? in.w0[tbase + slot] : 0xFFFFFFFFu;
-            }
-        } else
+        // unconditional loads (slots past the end of the last tile re-read its last record), padding selected afterwards:
+        // all 24 loads of a lane are in flight together
+        const u32 lastSlot = cnt - 1;
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
-            u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
-            bool ok = slot < cnt;
-            a0[r] = ok ? in.w0[tbase + slot] : 0xFFFFFFFFu;      // padding sorts last (digit 255, tile end)
-            u64 x12 = ok ? in.w12[tbase + slot] : 0xFFFFFFFFull;
+            const u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
+            const u64 src = tbase + (slot < lastSlot ? slot : lastSlot);
+            a0[r] = in.w0[src];
+            const u64 x12 = in.w12[src];
             a1[r] = (u32)x12;
             a2[r] = (u32)(x12 >> 32);
+        }
+#pragma unroll
+        for (int r = 0; r < RS_ROUNDS; r++) {
+            const u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
+            if (slot >= cnt) { a0[r] = 0xFFFFFFFFu; a1[r] = 0xFFFFFFFFu; a2[r] = 0u; }   // padding sorts last (digit 255, tile end)
         }
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
