@@ -22,6 +22,15 @@ __device__ __forceinline__ u64 bfq_permute64(u64 v, int dstLane)     // push to 
     return ((u64)hi << 32) | lo;
 }
 
+// Lanes of ONE wavefront exchange data through LDS across this point: the scheduling barrier is fenced so that the
+// compiler neither forwards a lane's own LDS value nor moves LDS accesses over it (free on a single wavefront).
+__device__ __forceinline__ void bfq_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // whole-wavefront shifts by one lane (DPP wave_shl / wave_shr, gfx9): VALU moves, no LDS round trip
 __device__ __forceinline__ u64 bfq_from_next_lane(u64 v)   // lane i <- lane i+1 (lane 63 <- 0)
 {

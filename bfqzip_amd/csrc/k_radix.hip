@@ -119,9 +119,9 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
             u32 before = (u32)__popcll(peers & ltmask);
             u32 c0 = wcnt[w][d];
             pk[r] = (d << 16) | (c0 + before);
-            __builtin_amdgcn_wave_barrier();
+            bfq_wave_sync();
             if (before == 0) wcnt[w][d] = c0 + (u32)__popcll(peers);
-            __builtin_amdgcn_wave_barrier();
+            bfq_wave_sync();
         }
         __syncthreads();
 

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
         // 1. segment heads from the sorted keys (+ LCP of this chunk's head rows): 4 rows per lane and step
         //    (16 B of w0, 32 B of w12), head bits OR-ed into LDS words in row order
         for (u32 i = lane; i < RF_HBW; i += 64) hb[i] = 0;
-        __builtin_amdgcn_wave_barrier();
+        bfq_wave_sync();
 #pragma unroll 1
         for (u32 g = 0; g < RF_HBW / 4; g++) {
             const u32 li0 = g * 256 + lane * 4;
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
             }
             atomicOr((unsigned long long *)&hb[g * 4 + (lane >> 4)], (unsigned long long)nib << (4 * (lane & 15)));
         }
-        __builtin_amdgcn_wave_barrier();
+        bfq_wave_sync();
         // 2. the chunk's segments of >= 2 rows, in row order, into LDS: one head word (64 rows) per lane
         u32 nsegs;
         {
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
             }
             nsegs = (u32)__builtin_amdgcn_readlane((int)incl, 63);
         }
-        __builtin_amdgcn_wave_barrier();
+        bfq_wave_sync();
         if (lane == 0 && nsegs) atomicAdd(&cnt->nSegs, (u64)nsegs);
         // 3. refinement: each wavefront takes 64 segments at a time
         for (u32 b0 = 0; b0 < nsegs; b0 += 64) {
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                 done += ntake;
             }
         }
-        __builtin_amdgcn_wave_barrier();                       // hb / segs are reused by the next chunk
+        bfq_wave_sync();                       // hb / segs are reused by the next chunk
     }
 }
 
