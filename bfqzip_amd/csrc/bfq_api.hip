@@ -252,6 +252,7 @@ static void fill_stats(bfq_ctx *c, bfq_stats *st)
 static size_t ws_need(u64 n, u64 N, u64 extra)
 {
     u64 nb = n / 32768 + 2;
+    if (nb < 8200) nb = 8200;                           // small sorts use smaller radix blocks: up to 8192 of them (bfq_radix_block_elems)
     size_t need = 0;
     need += 4 * (n + 256) + 24 * (n / 256 + 2) + 4096;  // bwt, qual, lcp16, symbol counts per group
     need += 8 * (n / 21 + 8);                           // packed text
@@ -315,7 +316,7 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16);
     u8 *T8 = (u8 *)A.w0, *Q8 = (u8 *)A.w12;             // dead before the sort's first scatter
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
-    u32 *hist0 = c->alloc<u32>(256 * ceil_div(n, BFQ_RS_BLOCK_ELEMS));
+    u32 *hist0 = c->alloc<u32>(256 * ceil_div(n, bfq_radix_block_elems(n)));
     bfq_build_keys(c, T8, Q8, text3, n, B, hist0);      // the records start in B: five passes later they are in A
     static_assert(BFQ_KEY_PASSES & 1, "an odd number of passes ends in the other buffer");
     bfq_radix_sort(c, B, A, n, BFQ_KEY_PASSES, hist0);

@@ -167,8 +167,18 @@ void bfq_exscan_u64(bfq_ctx *c, const u64 *in, u64 *out, u64 n, u64 *d_total);
 void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 n,
                     u8 *T8, u8 *Q8, u64 *text3, u64 nwords);
 // rows per radix workgroup (k_radix.hip); k_build_keys works on the same blocks to leave the first pass's digit counts
-#define BFQ_RS_BLOCK_ELEMS 98304
-void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0);   // hist0: [256][ceil(n / BFQ_RS_BLOCK_ELEMS)]
+#define BFQ_RS_BLOCK_ELEMS 98304                        // rows per radix block (and per text block of the pile counts) for large inputs
+#define BFQ_RS_TILE 3072                                // rows per scatter tile
+// rows per radix block of an n-row sort: a workgroup runs through its block tile by tile, so small inputs get smaller
+// blocks -- at least ~4 rounds of workgroups over the device instead of one round and a tail (1 M x 100 bp: 1028 blocks of
+// 98 304 rows on 1024 workgroup slots took two rounds)
+static inline u64 bfq_radix_block_elems(u64 n)
+{
+    u64 tpb = BFQ_RS_BLOCK_ELEMS / BFQ_RS_TILE;
+    while (tpb > 1 && n / (BFQ_RS_TILE * tpb) < 4096) tpb >>= 1;
+    return BFQ_RS_TILE * tpb;
+}
+void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0);   // hist0: [256][ceil(n / bfq_radix_block_elems(n))]
 // LSD radix sort of the records on their 48-bit key; result ends in A
 SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes = BFQ_KEY_PASSES, const u32 *hist0 = nullptr);   // returns the buffer holding the result (in: even passes, tmp: odd); fewer passes = low digits only; hist0: pass-0 counts already made
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp

@@ -21,20 +21,18 @@
 #define RS_OCC (1024 / RS_THREADS)                  // workgroups per CU (16 waves); 512-thread tiles measured 40 % slower
 #define RS_ROUNDS 12                                // items per thread
 #define RS_TILE (RS_THREADS * RS_ROUNDS)            // 3072 records per tile
-#define RS_TILES_PER_BLOCK 32
-#define RS_BLOCK_ELEMS ((u64)RS_TILE * RS_TILES_PER_BLOCK)
-static_assert(RS_TILE * RS_TILES_PER_BLOCK == BFQ_RS_BLOCK_ELEMS, "k_build_keys counts the first digit per radix block");
+static_assert(RS_TILE == BFQ_RS_TILE, "bfq_radix_block_elems() counts in scatter tiles");
 
 template <class T>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const T *__restrict__ dw, u64 n, int shift,
-                                                           u32 *__restrict__ hist, u64 nblocks)
+                                                           u32 *__restrict__ hist, u64 nblocks, u64 blockElems)
 {
     __shared__ u32 wh[RS_WAVES][256];
     u32 w = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < RS_WAVES * 256; i += RS_THREADS) (&wh[0][0])[i] = 0;
     __syncthreads();
-    u64 base = (u64)blockIdx.x * RS_BLOCK_ELEMS;
-    u64 end = base + RS_BLOCK_ELEMS;
+    u64 base = (u64)blockIdx.x * blockElems;
+    u64 end = base + blockElems;
     if (end > n) end = n;
     // 16 bytes per lane and load (4 or 2 records); the block base is a multiple of 4 records
     constexpr int V = 16 / sizeof(T);
@@ -65,7 +63,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const T *__restrict__
 // DW = which word carries the digit of this pass (0: w0, 1: w1)
 template <int DW>
 __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in, SortRec out, u64 n, int shift,
-                                                              const u64 *__restrict__ blockOff, u64 nblocks)
+                                                              const u64 *__restrict__ blockOff, u64 nblocks, u32 tilesPerBlock)
 {
     __shared__ u64 stage[RS_TILE];          // w0, then the (w1,w2) pair of the records
     __shared__ u8 dig[RS_TILE];             // digit of every tile-sorted slot
@@ -78,8 +76,8 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
     const u64 ltmask = bfq_lanemask_lt();
     if (tid < 256) gbase[tid] = blockOff[(u64)tid * nblocks + blockIdx.x];
 
-    for (int t = 0; t < RS_TILES_PER_BLOCK; t++) {
-        u64 tbase = (u64)blockIdx.x * RS_BLOCK_ELEMS + (u64)t * RS_TILE;
+    for (u32 t = 0; t < tilesPerBlock; t++) {
+        u64 tbase = ((u64)blockIdx.x * tilesPerBlock + t) * RS_TILE;
         if (tbase >= n) break;                                   // uniform
         u32 cnt = (n - tbase < (u64)RS_TILE) ? (u32)(n - tbase) : (u32)RS_TILE;
 
@@ -185,7 +183,9 @@ SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes, c
         }
         return (passes & 1) ? tmp : in;
     }
-    u64 nb = ceil_div(n, RS_BLOCK_ELEMS);
+    const u64 be = bfq_radix_block_elems(n);
+    const u32 tpb = (u32)(be / RS_TILE);
+    u64 nb = ceil_div(n, be);
     size_t m = c->mark();
     u32 *hist = c->alloc<u32>(256 * nb);
     u64 *off = c->alloc<u64>(256 * nb);
@@ -195,14 +195,14 @@ SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes, c
         const int shift = pass == 0 ? 24 : 8 * (pass - 1);
         const bool have = (pass == 0 && hist0);            // pass 0's counts were made by k_build_keys
         if (!have && dw)
-            KLAUNCH(c, K_RADIX_HIST, 8.0 * (double)n, k_radix_hist<u64>, nb, RS_THREADS, (const u64 *)in.w12, n, shift, hist, nb);
+            KLAUNCH(c, K_RADIX_HIST, 8.0 * (double)n, k_radix_hist<u64>, nb, RS_THREADS, (const u64 *)in.w12, n, shift, hist, nb, be);
         else if (!have)
-            KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist<u32>, nb, RS_THREADS, (const u32 *)in.w0, n, shift, hist, nb);
+            KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist<u32>, nb, RS_THREADS, (const u32 *)in.w0, n, shift, hist, nb, be);
         bfq_exscan_u32(c, have ? hist0 : hist, off, 256 * nb, nullptr);
         if (dw)
-            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb);
+            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb);
         else
-            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<0>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb);
+            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<0>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb);
         SortRec t = in; in = out; out = t;
     }
     c->release(m);

@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n,
 // one 16-byte (w0) and two 16-byte (w12) stores
 __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, const u8 *__restrict__ Q8,
                                                     const u64 *__restrict__ text3, u64 n, SortRec out, u32 *__restrict__ hist0,
-                                                    u64 nblocks)
+                                                    u64 nblocks, u64 blockElems)
 {
-    // One workgroup per radix block (BFQ_RS_BLOCK_ELEMS consecutive rows), 1024 rows per sweep: the digit counts of
+    // One workgroup per radix block (blockElems consecutive rows, a multiple of 1024), 1024 rows per sweep: the digit counts of
     // the sort's first pass come out on the way (per-wave LDS histograms), which saves that pass's 8 B/row histogram read.
     __shared__ u32 wh[4][256];
     const u32 w = threadIdx.x >> 6;
@@ -98,8 +98,8 @@ __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, c
     for (u64 hb = blockIdx.x; hb < nblocks; hb += gridDim.x) {
         for (int i = threadIdx.x; i < 4 * 256; i += 256) (&wh[0][0])[i] = 0;
         __syncthreads();
-        const u64 bbase = hb * (u64)BFQ_RS_BLOCK_ELEMS;
-        u64 bend = bbase + BFQ_RS_BLOCK_ELEMS;
+        const u64 bbase = hb * blockElems;
+        u64 bend = bbase + blockElems;
         if (bend > n) bend = n;
         u64 p0 = bbase + (u64)threadIdx.x * 4;
         u64 w0 = p0 / BFQ_SYMS_PER_WORD;
@@ -165,6 +165,7 @@ void bfq_pack_text(bfq_ctx *c, const u8 *T8, u64 n, u64 *text3, u64 nwords)
 void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0)
 {
     if (!n) return;
-    const u64 nb = ceil_div(n, BFQ_RS_BLOCK_ELEMS);
-    KLAUNCH(c, K_KEYS, 14.5 * (double)n, k_build_keys, bfq_grid(nb, 1), 256, T8, Q8, text3, n, out, hist0, nb);
+    const u64 be = bfq_radix_block_elems(n);
+    const u64 nb = ceil_div(n, be);
+    KLAUNCH(c, K_KEYS, 14.5 * (double)n, k_build_keys, bfq_grid(nb, 1), 256, T8, Q8, text3, n, out, hist0, nb, be);
 }
