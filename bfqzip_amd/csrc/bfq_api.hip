@@ -251,8 +251,7 @@ static void fill_stats(bfq_ctx *c, bfq_stats *st)
 // workspace bound for a collection of n rows (see DESIGN.md "HBM layout")
 static size_t ws_need(u64 n, u64 N, u64 extra)
 {
-    u64 nb = n / 32768 + 2;
-    if (nb < 8200) nb = 8200;                           // small sorts use smaller radix blocks: up to 8192 of them (bfq_radix_block_elems)
+    const u64 nb = ceil_div(n + 1, bfq_radix_block_elems(n)) + 8;   // small sorts use smaller radix blocks (bfq_radix_block_elems)
     size_t need = 0;
     need += 4 * (n + 256) + 24 * (n / 256 + 2) + 4096;  // bwt, qual, lcp16, symbol counts per group
     need += 8 * (n / 21 + 8);                           // packed text

@@ -154,7 +154,7 @@ extern "C" int bfq_glob_run_pile(bfq_ctx *c, const uint8_t *d_T8, const uint8_t 
         if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^37 rows)"};
         // text3 + block counts + one pile of at most n rows: sized generously from n (a pile holds about n / 16)
         const u64 cap = n / 4 + (1u << 20);
-        c->reserve(8 * (n / 21 + 8) + 40 * (n / BFQ_RS_BLOCK_ELEMS + 64) * 8 + 30 * (cap + 256) + 12 * 256 * (cap / 32768 + 8200) + (cap + 4096) / 32768 * 64 + (128u << 20));
+        c->reserve(8 * (n / 21 + 8) + 40 * (n / BFQ_RS_BLOCK_ELEMS + 64) * 8 + 30 * (cap + 256) + 12 * 256 * (ceil_div(cap + 1, bfq_radix_block_elems(cap)) + 8200) + (cap + 4096) / 32768 * 64 + (128u << 20));
         c->zeroCounters();
         const u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
         u64 *text3 = c->alloc<u64>(nwords);

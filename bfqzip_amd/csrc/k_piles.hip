@@ -151,8 +151,7 @@ __global__ void k_refine_reset(DevCounters *cnt)
 // workspace bound of the pile mode (pile records for at most `cap` rows)
 size_t bfq_ws_need_piles(u64 n, u64 N, u64 cap, u64 extra)
 {
-    u64 nb = n / 32768 + 2, nbc = cap / 32768 + 2;
-    if (nbc < 8200) nbc = 8200;                                  // small sorts use smaller radix blocks (bfq_radix_block_elems)
+    u64 nb = n / 32768 + 2, nbc = ceil_div(cap + 1, bfq_radix_block_elems(cap)) + 8200;   // a smaller pile may use smaller radix blocks
     size_t need = 0;
     need += 4 * (n + 256) + 4096;                                // bwt, qual, lcp16
     need += 8 * (n / 21 + 8) + 2 * (n + 256);                    // packed text, T8, Q8
@@ -192,7 +191,7 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     if (N) KLAUNCH(c, K_EMIT, 12.0 * (double)N, k_term_pile, bfq_grid(N, 256), 256, (const u8 *)T8, (const u8 *)Q8, d_roff, N,
                    (u32)(termOut & 0xFF), c->d_bwt, c->d_qual, c->d_lcp);
     const size_t avail = c->wsCap - c->wsTop;
-    auto fits = [&](u64 m) { return (size_t)(24 * (m + 256) + 12 * 256 * (m / 32768 + 8200) + (m / 32768 + 4096) * 64 + (48u << 20)) <= avail; };
+    auto fits = [&](u64 m) { return (size_t)(24 * (m + 256) + 12 * 256 * (ceil_div(m + 1, bfq_radix_block_elems(m)) + 8) + (m / 32768 + 4096) * 64 + (48u << 20)) <= avail; };
     // one pile (first symbol s, second symbol s2 or 7 = any) of m suffixes -> rows [start, start + m)
     auto run_pile = [&](u32 s, u32 s2, u64 m, u64 start, const u64 *off) {
         const size_t mp = c->mark();
