@@ -21,6 +21,8 @@ SYMBOLS = [
     "bfq_glob_begin", "bfq_glob_local_text", "bfq_glob_pile_counts", "bfq_glob_init_out", "bfq_glob_run_pile", "bfq_glob_finish",
     "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device", "bfq_synth_fastq",
     "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
+    "bfq_stream_bound", "bfq_stream_raw_len", "bfq_stream_compress", "bfq_stream_decompress",
+    "bfq_stream_reserve", "bfq_stream_compress_device",
     "bfq_workspace_bytes", "bfq_version",
 ]
 
@@ -132,6 +134,14 @@ def lib():
         L.bfq_synth_host.argtypes = [C.POINTER(Synth), vp, vp, vp]
         L.bfq_synth_device.argtypes = [vp, C.POINTER(Synth), vp, vp, vp]
         L.bfq_synth_fastq.argtypes = [vp, C.POINTER(Synth), vp, u64, C.POINTER(u64)]
+        L.bfq_stream_bound.restype = u64
+        L.bfq_stream_bound.argtypes = [u64]
+        L.bfq_stream_raw_len.restype = C.c_int64
+        L.bfq_stream_raw_len.argtypes = [vp, u64]
+        L.bfq_stream_compress.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+        L.bfq_stream_decompress.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
+        L.bfq_stream_reserve.argtypes = [vp, u64]
+        L.bfq_stream_compress_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
         L.bfq_prof_enable.argtypes = [vp, C.c_int]
         L.bfq_prof_reset.argtypes = [vp]
         L.bfq_prof_count.argtypes = [vp]

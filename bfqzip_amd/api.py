@@ -347,6 +347,41 @@ class Engine:
         self._ck(self.L.bfq_synth_fastq(self.h, C.byref(spec), _ptr(out), len(out), C.byref(ol)))
         return int(ol.value)
 
+    # ---- stream codec (step 5 of the reference: BFQzip.py:253-275)
+    def stream_compress(self, data, out=None):
+        """BFQRANS1 container of the bytes `data` (uint8 array); returns a uint8 array (a view of `out` when given)."""
+        data = _u8(data)
+        cap = int(self.L.bfq_stream_bound(len(data)))
+        if out is None:
+            out = np.empty(cap, np.uint8)
+        ol = C.c_uint64(0)
+        self._ck(self.L.bfq_stream_compress(self.h, _ptr(data), len(data), _ptr(out), len(out), C.byref(ol)))
+        return out[:int(ol.value)]
+
+    def stream_decompress(self, blob, out=None):
+        """The raw bytes of a BFQRANS1 container."""
+        blob = _u8(blob)
+        n = int(self.L.bfq_stream_raw_len(_ptr(blob), len(blob)))
+        if n < 0:
+            raise BfqError(-1, "not a BFQRANS1 stream")
+        if out is None:
+            out = np.empty(max(n, 1), np.uint8)
+        ol = C.c_uint64(0)
+        self._ck(self.L.bfq_stream_decompress(self.h, _ptr(blob), len(blob), _ptr(out), len(out), C.byref(ol)))
+        return out[:int(ol.value)]
+
+    def stream_compress_device(self, d_in, n, d_out, cap):
+        """Device-resident form (after stream_reserve(n)); returns the container's length."""
+        ol = C.c_uint64(0)
+        self._ck(self.L.bfq_stream_compress_device(self.h, d_in, n, d_out, cap, C.byref(ol)))
+        return int(ol.value)
+
+    def stream_reserve(self, n):
+        self._ck(self.L.bfq_stream_reserve(self.h, n))
+
+    def stream_bound(self, n):
+        return int(self.L.bfq_stream_bound(n))
+
     # ---- profiling
     def prof_reset(self):
         self.L.bfq_prof_reset(self.h)

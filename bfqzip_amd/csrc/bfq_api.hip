@@ -959,3 +959,53 @@ extern "C" int bfq_synth_fastq(bfq_ctx *c, const bfq_synth *s, uint8_t *h_out, u
         c->profCollect();
     });
 }
+
+// ---------------------------------------------------------------- stream codec (BFQzip.py:253-275)
+extern "C" uint64_t bfq_stream_bound(uint64_t len) { return bfq_codec_bound(len); }
+extern "C" int64_t bfq_stream_raw_len(const uint8_t *h_in, uint64_t len)
+{
+    try { return (int64_t)bfq_codec_raw_len(h_in, len); } catch (const BfqError &) { return -1; }
+}
+extern "C" int bfq_stream_compress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len)
+{
+    return guarded(c, [&] {
+        if ((len && !h_in) || !h_out || !out_len) throw BfqError{BFQ_E_ARG, "null argument"};
+        c->reserve(bfq_codec_workspace(len));
+        u8 *d_in = c->alloc<u8>(len + 16);
+        const u64 bound = bfq_codec_bound(len) < cap ? bfq_codec_bound(len) : cap;
+        u8 *d_out = c->alloc<u8>(bound + 16);
+        if (len) bfq_upload(c, d_in, h_in, len);
+        const u64 got = bfq_codec_compress_device(c, d_in, len, d_out, bound);
+        bfq_download(c, h_out, d_out, got);
+        c->profCollect();
+        *out_len = got;
+    });
+}
+extern "C" int bfq_stream_decompress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len)
+{
+    return guarded(c, [&] {
+        if (!h_in || !out_len) throw BfqError{BFQ_E_ARG, "null argument"};
+        const u64 raw = bfq_codec_raw_len(h_in, len);
+        if (raw > cap || (raw && !h_out)) throw BfqError{BFQ_E_ARG, "output buffer too small for the raw stream"};
+        c->reserve(bfq_codec_workspace(raw) + len);
+        u8 *d_in = c->alloc<u8>(len + 16), *d_out = c->alloc<u8>(raw + 16);
+        bfq_upload(c, d_in, h_in, len);
+        const u64 got = bfq_codec_decompress_device(c, h_in, d_in, len, d_out, raw);
+        if (got) bfq_download(c, h_out, d_out, got);
+        c->profCollect();
+        *out_len = got;
+    });
+}
+// both buffers on the device (what bench.py times); the workspace is reserved by bfq_stream_reserve first
+extern "C" int bfq_stream_reserve(bfq_ctx *c, uint64_t len)
+{
+    return guarded(c, [&] { c->reserve(bfq_codec_workspace(len)); });
+}
+extern "C" int bfq_stream_compress_device(bfq_ctx *c, const uint8_t *d_in, uint64_t len, uint8_t *d_out, uint64_t cap, uint64_t *out_len)
+{
+    return guarded(c, [&] {
+        c->wsTop = 0;
+        *out_len = bfq_codec_compress_device(c, d_in, len, d_out, cap);
+        c->profCollect();
+    });
+}

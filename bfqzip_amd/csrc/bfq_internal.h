@@ -164,6 +164,13 @@ void bfq_exscan_u8(bfq_ctx *c, const u8 *in, u64 *out, u64 n, u64 *d_total);
 void bfq_exscan_u32(bfq_ctx *c, const u32 *in, u64 *out, u64 n, u64 *d_total);
 void bfq_exscan_u64(bfq_ctx *c, const u64 *in, u64 *out, u64 n, u64 *d_total);
 
+// stream codec (k_codec.hip)
+u64 bfq_codec_bound(u64 n);
+u64 bfq_codec_workspace(u64 n);
+u64 bfq_codec_raw_len(const u8 *h_in, u64 len);
+u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap);
+u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap);
+
 // step 1 pieces
 void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 n,
                     u8 *T8, u8 *Q8, u64 *text3, u64 nwords);

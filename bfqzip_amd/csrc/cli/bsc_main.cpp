@@ -1,0 +1,39 @@
+// bsc_main.cpp -- drop-in for the command line BFQzip.py hands every output stream to in step 5b
+// (`external/libbsc/bsc e <stream> <stream>.bsc -T`, BFQzip.py:23,265-275):
+//     bsc e INPUT OUTPUT [options]     compress   (libbsc's options are accepted and ignored: the codec has none)
+//     bsc d INPUT OUTPUT [options]     decompress
+// The container is this project's BFQRANS1 (include/bfqzip_hip.h, oracle/bfq_codec_ref.c), written by the GPU codec;
+// it is NOT libbsc's format (libbsc is an empty submodule of the reference tree).  Exit status 0 on success.
+#include "cli_common.h"
+
+int main(int argc, char **argv)
+{
+    if (argc < 4 || (strcmp(argv[1], "e") && strcmp(argv[1], "d"))) {
+        fprintf(stderr, "usage: %s e|d INPUT OUTPUT [options]\n", argv[0]);
+        return 1;
+    }
+    const bool enc = !strcmp(argv[1], "e");
+    std::vector<uint8_t> in;
+    if (!read_file(argv[2], in)) { fprintf(stderr, "bsc: cannot read %s\n", argv[2]); return 1; }
+    bfq_params P;
+    bfq_default_params(&P);
+    bfq_ctx *c = bfq_create(0, &P);
+    if (!c) { fprintf(stderr, "bsc: %s\n", bfq_create_error()); return 1; }
+    uint64_t cap;
+    if (enc) cap = bfq_stream_bound(in.size());
+    else {
+        const int64_t raw = bfq_stream_raw_len(in.data(), in.size());
+        if (raw < 0) { fprintf(stderr, "bsc: %s is not a BFQRANS1 stream\n", argv[2]); bfq_destroy(c); return 1; }
+        cap = (uint64_t)raw;
+    }
+    std::vector<uint8_t> out(cap ? cap : 1);
+    uint64_t got = 0;
+    const int rc = enc ? bfq_stream_compress(c, in.data(), in.size(), out.data(), out.size(), &got)
+                       : bfq_stream_decompress(c, in.data(), in.size(), out.data(), out.size(), &got);
+    if (rc) { fprintf(stderr, "bsc: %s\n", bfq_last_error(c)); bfq_destroy(c); return 1; }
+    bfq_destroy(c);
+    if (!write_file(argv[3], out.data(), got)) { fprintf(stderr, "bsc: cannot write %s\n", argv[3]); return 1; }
+    if (enc) printf("%s compressed %llu into %llu in BFQRANS1 (GPU static order-k model + rANS)\n", argv[2], (unsigned long long)in.size(), (unsigned long long)got);
+    else printf("%s decompressed %llu into %llu\n", argv[2], (unsigned long long)in.size(), (unsigned long long)got);
+    return 0;
+}

@@ -1,0 +1,370 @@
+// k_codec.hip -- the stream codec: entropy coding of OUT.fq.dna / OUT.fq.qs / OUT.h on the GPU, the step the
+// reference hands to external tools (`7z a -mm=PPMd`, `bsc e ... -T`: step5 / step5b, BFQzip.py:253-275).
+// SURVEY 8(f).4.  The container is this project's own (neither 7z nor libbsc sources are in the reference tree):
+// a static order-k model of the whole stream + range-ANS, every segment of 8192 symbols on its own, so that
+// encoder and decoder run one segment per lane.  oracle/bfq_codec_ref.c states the format and is what
+// the tests compare this file with, byte for byte.
+//
+//   k_cdc_present : which byte values occur                                  (alphabet, dense symbol numbers)
+//   k_cdc_count   : occurrences of every (context, symbol) pair; a lane walks its segment forwards and adds up
+//                   runs of equal pairs before it touches the table (smoothed quality streams are long runs:
+//                   one atomic per run, not per symbol)
+//   host          : k, the model rows (normalised to 2^12), the cumulative rows -- the table is at most 4 M entries
+//   k_cdc_encode  : a lane codes its segment last symbol to first (the context in front of every symbol follows
+//                   from the one behind it without a second pass), bytes stored backwards into its scratch slot
+//   k_cdc_pack    : the slots' streams closed up behind the header (one wavefront per segment)
+//   k_cdc_decode  : a lane decodes its segment forwards
+// Integer work, bound by the dependent table look-up per symbol; the input is read once per pass.
+#include <string.h>
+#include "bfq_internal.h"
+#include "bfq_device.h"
+
+#define CQ_SEG 8192u
+#define CQ_SCALE 12u
+#define CQ_L (1u << 23)
+#define CQ_SLOT (2u * CQ_SEG + 16u)                  // scratch bytes per segment (a symbol costs at most 12 bits)
+#define CQ_MAX_TABLE (1u << 22)
+
+__global__ __launch_bounds__(256) void k_cdc_present(const u8 *__restrict__ in, u64 n, u32 *__restrict__ present)
+{
+    __shared__ u32 sh[256];
+    sh[threadIdx.x] = 0;
+    __syncthreads();
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (u64)gridDim.x * blockDim.x) sh[in[i]] = 1;
+    __syncthreads();
+    if (sh[threadIdx.x]) present[threadIdx.x] = 1;
+}
+
+struct CdcModel {
+    u32 A, k, nseg;
+    u32 top;                 // A^k
+    u64 n;
+};
+
+// the k symbols in front of a position, newest in the low byte: the symbol that leaves the context is byte k-1
+__device__ __forceinline__ u32 cdc_next_ctx(u32 ctx, u32 s, u64 &win, const CdcModel &m)
+{
+    if (!m.k) return 0;
+    const u32 outgoing = (u32)(win >> (8u * (m.k - 1u))) & 0xFFu;
+    win = (win << 8) | s;
+    return ctx * m.A + s - outgoing * m.top;
+}
+
+__global__ __launch_bounds__(256) void k_cdc_count(const u8 *__restrict__ in, const u8 *__restrict__ map, CdcModel m,
+                                                   u32 *__restrict__ cnt)
+{
+    __shared__ u8 smap[256];
+    smap[threadIdx.x] = map[threadIdx.x];
+    __syncthreads();
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < m.nseg; g += (u64)gridDim.x * blockDim.x) {
+        const u64 b = g * CQ_SEG, e = (b + CQ_SEG < m.n) ? b + CQ_SEG : m.n;
+        u32 ctx = 0, lastKey = 0xFFFFFFFFu, run = 0;
+        u64 win = 0;
+        for (u64 i = b; i < e; i++) {
+            const u32 s = smap[in[i]];
+            const u32 key = ctx * m.A + s;
+            if (key == lastKey) run++;
+            else { if (run) atomicAdd(&cnt[lastKey], run); lastKey = key; run = 1; }
+            ctx = cdc_next_ctx(ctx, s, win, m);
+        }
+        if (run) atomicAdd(&cnt[lastKey], run);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cdc_encode(const u8 *__restrict__ in, const u8 *__restrict__ map, CdcModel m,
+                                                    const u16 *__restrict__ freq, const u16 *__restrict__ cum,
+                                                    u8 *__restrict__ scratch, u32 *__restrict__ segBytes)
+{
+    __shared__ u8 smap[256];
+    smap[threadIdx.x] = map[threadIdx.x];
+    __syncthreads();
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < m.nseg; g += (u64)gridDim.x * blockDim.x) {
+        const u64 b = g * CQ_SEG, e = (b + CQ_SEG < m.n) ? b + CQ_SEG : m.n;
+        // context in front of the last symbol
+        u32 ctx = 0;
+        if (m.k) {
+            const u64 len = e - b;
+            for (u64 i = (len - 1 > m.k ? e - 1 - m.k : b); i + 1 < e; i++) ctx = (ctx * m.A + smap[in[i]]) % m.top;
+        }
+        u8 *const slotEnd = scratch + (g + 1) * (u64)CQ_SLOT;
+        u8 *q = slotEnd;
+        u32 x = CQ_L;
+        u32 s = smap[in[e - 1]];
+        for (u64 i = e; i-- > b;) {
+            const u32 f = freq[(u64)ctx * m.A + s], c0 = cum[(u64)ctx * m.A + s];
+            const u32 xmax = ((CQ_L >> CQ_SCALE) << 8) * f;
+            while (x >= xmax) { *--q = (u8)x; x >>= 8; }
+            x = ((x / f) << CQ_SCALE) + (x % f) + c0;
+            if (i > b) {                                           // the symbol in front, and the context in front of it
+                const u32 prev = smap[in[i - 1]];
+                if (m.k) {
+                    const u32 incoming = (i - 1 >= b + m.k) ? smap[in[i - 1 - m.k]] : 0u;
+                    ctx = (ctx + incoming * m.top - prev) / m.A;
+                }
+                s = prev;
+            }
+        }
+        q -= 4;
+        q[0] = (u8)x; q[1] = (u8)(x >> 8); q[2] = (u8)(x >> 16); q[3] = (u8)(x >> 24);
+        segBytes[g] = (u32)(slotEnd - q);
+    }
+}
+
+// one wavefront per segment: its stream from the end of its scratch slot to its place in the output
+__global__ __launch_bounds__(256) void k_cdc_pack(const u8 *__restrict__ scratch, const u32 *__restrict__ segBytes,
+                                                  const u64 *__restrict__ off, u32 nseg, u8 *__restrict__ out)
+{
+    const u32 lane = bfq_lane();
+    const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
+    for (u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < nseg; g += nwaves) {
+        const u32 bytes = segBytes[g];
+        const u8 *src = scratch + (g + 1) * (u64)CQ_SLOT - bytes;
+        u8 *dst = out + off[g];
+        for (u32 j = lane; j < bytes; j += 64) dst[j] = src[j];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cdc_decode(const u8 *__restrict__ pay, const u64 *__restrict__ off,
+                                                    const u32 *__restrict__ segBytes, const u8 *__restrict__ alphabet, CdcModel m,
+                                                    const u16 *__restrict__ freq, const u16 *__restrict__ cum,
+                                                    u8 *__restrict__ out, u32 *__restrict__ bad)
+{
+    __shared__ u8 salpha[256];
+    salpha[threadIdx.x] = alphabet[threadIdx.x];
+    __syncthreads();
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < m.nseg; g += (u64)gridDim.x * blockDim.x) {
+        const u8 *q = pay + off[g], *const qe = q + segBytes[g];
+        u32 x = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+        q += 4;
+        const u64 b = g * CQ_SEG, e = (b + CQ_SEG < m.n) ? b + CQ_SEG : m.n;
+        u32 ctx = 0;
+        u64 win = 0;
+        bool ok = true;
+        for (u64 i = b; i < e && ok; i++) {
+            const u32 slot = x & ((1u << CQ_SCALE) - 1u);
+            const u16 *fr = freq + (u64)ctx * m.A, *cu = cum + (u64)ctx * m.A;
+            u32 s = 0;
+            if (m.A <= 16) {
+                while (s < m.A && !(fr[s] && slot < (u32)cu[s] + fr[s])) s++;
+            } else {                                               // last symbol whose cumulative count is <= slot, then back over absent ones
+                u32 lo = 0, hi = m.A;
+                while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((u32)cu[mid] <= slot) lo = mid; else hi = mid; }
+                s = lo;
+                while (s > 0 && fr[s] == 0) s--;
+                if (!(fr[s] && slot >= (u32)cu[s] && slot < (u32)cu[s] + fr[s])) s = m.A;
+            }
+            if (s >= m.A) { ok = false; break; }
+            x = fr[s] * (x >> CQ_SCALE) + slot - cu[s];
+            while (x < CQ_L) { if (q >= qe) { ok = false; break; } x = (x << 8) | *q++; }
+            out[i] = salpha[s];
+            ctx = cdc_next_ctx(ctx, s, win, m);
+        }
+        if (!ok) atomicAdd(bad, 1u);
+    }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------
+static u32 cdc_choose_k(u32 A, u64 n)
+{
+    u64 limit = n >> 4;
+    if (limit < 4096) limit = 4096;
+    if (limit > CQ_MAX_TABLE) limit = CQ_MAX_TABLE;
+    u32 k = 0;
+    u64 p = (u64)A * A;
+    while (k < 8 && p <= limit) { k++; p *= A; }
+    return k;
+}
+static void cdc_normalise(const u32 *cnt, u32 A, u16 *f)
+{
+    const u32 M = 1u << CQ_SCALE;
+    u64 T = 0;
+    for (u32 s = 0; s < A; s++) T += cnt[s];
+    u32 sum = 0;
+    for (u32 s = 0; s < A; s++) {
+        u32 v = 0;
+        if (cnt[s]) { v = (u32)(((u64)cnt[s] * M) / T); if (v == 0) v = 1; }
+        f[s] = (u16)v; sum += v;
+    }
+    while (sum > M) {
+        u32 best = 0;
+        for (u32 s = 1; s < A; s++) if (f[s] > f[best]) best = s;
+        u32 d = sum - M;
+        if (d > (u32)f[best] - 1u) d = (u32)f[best] - 1u;
+        f[best] = (u16)(f[best] - d); sum -= d;
+    }
+    if (sum < M) {
+        u32 best = 0;
+        for (u32 s = 1; s < A; s++) if (f[s] > f[best]) best = s;
+        f[best] = (u16)(f[best] + (M - sum));
+    }
+}
+static void put32(u8 *p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); p[3] = (u8)(v >> 24); }
+static void put64(u8 *p, u64 v) { put32(p, (u32)v); put32(p + 4, (u32)(v >> 32)); }
+static u32 get32(const u8 *p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
+static u64 get64(const u8 *p) { return (u64)get32(p) | ((u64)get32(p + 4) << 32); }
+
+// upper bound of a container for n raw bytes (what callers size their output buffers with)
+u64 bfq_codec_bound(u64 n)
+{
+    const u64 nseg = (n + CQ_SEG - 1) / CQ_SEG;
+    return 36 + 256 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64;
+}
+// device workspace of one compress / decompress call
+u64 bfq_codec_workspace(u64 n)
+{
+    const u64 nseg = (n + CQ_SEG - 1) / CQ_SEG;
+    return n + bfq_codec_bound(n) + nseg * (u64)CQ_SLOT + 16ull * CQ_MAX_TABLE + 24 * nseg + (64u << 20);
+}
+
+// d_in: n raw bytes on the device.  The container goes to d_out (capacity cap); returns its length.
+u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
+{
+    const size_t mk = c->mark();
+    u32 *d_present = c->alloc<u32>(256);
+    HIP_CHECK(hipMemsetAsync(d_present, 0, 1024, c->stream));
+    if (n) KLAUNCH(c, K_MISC, (double)n, k_cdc_present, bfq_grid(n, 256 * 64), 256, d_in, n, d_present);
+    u32 present[256];
+    HIP_CHECK(hipMemcpyAsync(present, d_present, 1024, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    u8 alphabet[256] = {0}, map[256] = {0};
+    u32 A = 0;
+    for (u32 b = 0; b < 256; b++) if (present[b]) { map[b] = (u8)A; alphabet[A++] = (u8)b; }
+    if (A == 0) A = 1;
+    CdcModel m;
+    m.A = A; m.k = cdc_choose_k(A, n); m.n = n; m.nseg = (u32)((n + CQ_SEG - 1) / CQ_SEG);
+    u64 nctx = 1;
+    for (u32 j = 0; j < m.k; j++) nctx *= A;
+    m.top = (u32)nctx;
+    const u64 E = nctx * A;
+    u8 *d_map = c->alloc<u8>(256);
+    HIP_CHECK(hipMemcpyAsync(d_map, map, 256, hipMemcpyHostToDevice, c->stream));
+    u32 *d_cnt = c->alloc<u32>(E);
+    HIP_CHECK(hipMemsetAsync(d_cnt, 0, 4 * E, c->stream));
+    if (n) KLAUNCH(c, K_MISC, (double)n, k_cdc_count, bfq_grid(m.nseg, 256), 256, d_in, (const u8 *)d_map, m, d_cnt);
+    std::vector<u32> cnt(E);
+    HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, 4 * E, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    std::vector<u16> freq(E, 0), cum(E, 0);
+    std::vector<u8> used((nctx + 7) / 8, 0);
+    u64 nused = 0;
+    for (u64 x = 0; x < nctx; x++) {
+        u64 T = 0;
+        for (u32 s = 0; s < A; s++) T += cnt[x * A + s];
+        if (!T) continue;
+        nused++;
+        used[x >> 3] |= (u8)(1u << (x & 7));
+        cdc_normalise(cnt.data() + x * A, A, freq.data() + x * A);
+        u32 acc = 0;
+        for (u32 s = 0; s < A; s++) { cum[x * A + s] = (u16)acc; acc += freq[x * A + s]; }
+    }
+    const u64 hdr = 36 + 256 + used.size() + nused * A * 2 + 4ull * m.nseg;
+    if (hdr > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
+    u16 *d_freq = c->alloc<u16>(E), *d_cum = c->alloc<u16>(E);
+    HIP_CHECK(hipMemcpyAsync(d_freq, freq.data(), 2 * E, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(d_cum, cum.data(), 2 * E, hipMemcpyHostToDevice, c->stream));
+    u32 *d_segBytes = c->alloc<u32>(m.nseg + 1);
+    u64 *d_off = c->alloc<u64>(m.nseg + 1), *d_total = c->alloc<u64>(1);
+    u8 *scratch = c->alloc<u8>((u64)m.nseg * CQ_SLOT + 16);
+    u64 total = 0;
+    std::vector<u32> segBytes(m.nseg);
+    if (m.nseg) {
+        KLAUNCH(c, K_MISC, 3.0 * (double)n, k_cdc_encode, bfq_grid(m.nseg, 256), 256, d_in, (const u8 *)d_map, m, (const u16 *)d_freq,
+                (const u16 *)d_cum, scratch, d_segBytes);
+        bfq_exscan_u32(c, d_segBytes, d_off, m.nseg, d_total);
+        HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_CHECK(hipMemcpyAsync(segBytes.data(), d_segBytes, 4ull * m.nseg, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+        if (hdr + total > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
+        KLAUNCH(c, K_MISC, 2.0 * (double)total, k_cdc_pack, bfq_grid((u64)m.nseg * 64, 256), 256, (const u8 *)scratch, (const u32 *)d_segBytes,
+                (const u64 *)d_off, m.nseg, d_out + hdr);
+    }
+    std::vector<u8> h(hdr);
+    u8 *p = h.data();
+    memcpy(p, "BFQRANS1", 8); put64(p + 8, n);
+    put32(p + 16, CQ_SEG); put32(p + 20, m.nseg); put32(p + 24, A); put32(p + 28, m.k); put32(p + 32, CQ_SCALE);
+    memcpy(p + 36, alphabet, 256);
+    memcpy(p + 36 + 256, used.data(), used.size());
+    u8 *rows = p + 36 + 256 + used.size();
+    for (u64 x = 0; x < nctx; x++) {
+        if (!((used[x >> 3] >> (x & 7)) & 1)) continue;
+        for (u32 s = 0; s < A; s++) { rows[0] = (u8)freq[x * A + s]; rows[1] = (u8)(freq[x * A + s] >> 8); rows += 2; }
+    }
+    for (u32 g = 0; g < m.nseg; g++) put32(rows + 4ull * g, segBytes[g]);
+    HIP_CHECK(hipMemcpyAsync(d_out, h.data(), hdr, hipMemcpyHostToDevice, c->stream));
+    c->sync();
+    c->release(mk);
+    return hdr + total;
+}
+
+// h_hdr: the first bytes of a container (at least min(len, bfq_codec_header_bound()) of them) on the host.
+// Parses the header; returns its length and the raw length.
+struct CdcHeader { CdcModel m; u64 hdr; std::vector<u8> alphabet; std::vector<u16> freq, cum; std::vector<u32> segBytes; };
+static void cdc_parse(const u8 *in, u64 len, CdcHeader &H)
+{
+    const BfqError bad{BFQ_E_ARG, "not a BFQRANS1 stream (or a damaged one)"};
+    if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) throw bad;
+    CdcModel &m = H.m;
+    m.n = get64(in + 8);
+    const u32 seg = get32(in + 16), scale = get32(in + 32);
+    m.nseg = get32(in + 20); m.A = get32(in + 24); m.k = get32(in + 28);
+    if (seg != CQ_SEG || scale != CQ_SCALE || m.A == 0 || m.A > 256 || m.k > 8 || m.nseg != (m.n + seg - 1) / seg) throw bad;
+    u64 nctx = 1;
+    for (u32 j = 0; j < m.k; j++) { nctx *= m.A; if (nctx > CQ_MAX_TABLE) throw bad; }
+    if (nctx * m.A > CQ_MAX_TABLE) throw bad;
+    m.top = (u32)nctx;
+    H.alphabet.assign(in + 36, in + 36 + 256);
+    const u8 *used = in + 36 + 256;
+    if (36 + 256 + (nctx + 7) / 8 > len) throw bad;
+    const u8 *rows = used + (nctx + 7) / 8;
+    H.freq.assign(nctx * m.A, 0); H.cum.assign(nctx * m.A, 0);
+    for (u64 x = 0; x < nctx; x++) {
+        if (!((used[x >> 3] >> (x & 7)) & 1)) continue;
+        if ((u64)(rows - in) + 2ull * m.A > len) throw bad;
+        u32 acc = 0;
+        for (u32 s = 0; s < m.A; s++) { H.freq[x * m.A + s] = (u16)(rows[0] | (rows[1] << 8)); rows += 2; H.cum[x * m.A + s] = (u16)acc; acc += H.freq[x * m.A + s]; }
+        if (acc != (1u << CQ_SCALE)) throw bad;
+    }
+    if ((u64)(rows - in) + 4ull * m.nseg > len) throw bad;
+    H.segBytes.resize(m.nseg);
+    u64 total = 0;
+    for (u32 g = 0; g < m.nseg; g++) { H.segBytes[g] = get32(rows + 4ull * g); if (H.segBytes[g] < 4) throw bad; total += H.segBytes[g]; }
+    H.hdr = (u64)(rows - in) + 4ull * m.nseg;
+    if (H.hdr + total > len) throw bad;
+}
+
+u64 bfq_codec_raw_len(const u8 *h_in, u64 len)
+{
+    if (len < 36 + 256 || memcmp(h_in, "BFQRANS1", 8)) throw BfqError{BFQ_E_ARG, "not a BFQRANS1 stream"};
+    return get64(h_in + 8);
+}
+
+// h_in: the whole container on the host (its header is parsed there), d_in: the same bytes on the device.
+// The raw bytes go to d_out (capacity cap); returns their number.
+u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap)
+{
+    CdcHeader H;
+    cdc_parse(h_in, len, H);
+    const CdcModel &m = H.m;
+    if (m.n > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the raw stream"};
+    if (!m.nseg) return 0;
+    const size_t mk = c->mark();
+    const u64 E = (u64)m.top * m.A;
+    u16 *d_freq = c->alloc<u16>(E), *d_cum = c->alloc<u16>(E);
+    u8 *d_alpha = c->alloc<u8>(256);
+    u32 *d_segBytes = c->alloc<u32>(m.nseg + 1), *d_bad = c->alloc<u32>(1);
+    u64 *d_off = c->alloc<u64>(m.nseg + 1);
+    HIP_CHECK(hipMemcpyAsync(d_freq, H.freq.data(), 2 * E, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(d_cum, H.cum.data(), 2 * E, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(d_alpha, H.alphabet.data(), 256, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemcpyAsync(d_segBytes, H.segBytes.data(), 4ull * m.nseg, hipMemcpyHostToDevice, c->stream));
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, c->stream));
+    bfq_exscan_u32(c, d_segBytes, d_off, m.nseg, nullptr);
+    KLAUNCH(c, K_MISC, 3.0 * (double)m.n, k_cdc_decode, bfq_grid(m.nseg, 256), 256, d_in + H.hdr, (const u64 *)d_off, (const u32 *)d_segBytes,
+            (const u8 *)d_alpha, m, (const u16 *)d_freq, (const u16 *)d_cum, d_out, d_bad);
+    u32 bad = 0;
+    HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->release(mk);
+    if (bad) throw BfqError{BFQ_E_ARG, "damaged BFQRANS1 stream"};
+    return m.n;
+}

@@ -226,6 +226,21 @@ int bfq_synth_device(bfq_ctx *c, const bfq_synth *s, uint8_t *d_bases, uint8_t *
  * formatted on the device, copied to h_out (cap >= N * (2 * Lmax + 30) is always enough). */
 int bfq_synth_fastq(bfq_ctx *c, const bfq_synth *s, uint8_t *h_out, uint64_t cap, uint64_t *out_len);
 
+/* ---- stream codec: entropy coding of OUT.fq.dna / OUT.fq.qs / OUT.h on the GPU.
+ * Replaces step 5 of the reference, which hands every stream to an external tool: `7z a -mm=PPMd <f>.7z <f>`
+ * (step5, BFQzip.py:253-263) or `external/libbsc/bsc e <f> <f>.bsc -T` (step5b, BFQzip.py:265-275).  The front-end
+ * dropin/external/libbsc/bsc takes that command line (`bsc e IN OUT [options]`, `bsc d IN OUT`).
+ * The container ("BFQRANS1": static order-k model + range-ANS, segments of 8192 symbols) is this project's own --
+ * neither 7z nor libbsc are part of the reference tree -- and is stated in oracle/bfq_codec_ref.c.
+ * Any bytes compress (the model adapts to the alphabet it finds); host buffers in and out. */
+uint64_t bfq_stream_bound(uint64_t len);                          /* capacity that always suffices for `len` raw bytes */
+int64_t  bfq_stream_raw_len(const uint8_t *h_in, uint64_t len);   /* raw length of a container, -1 if it is not one  */
+int bfq_stream_compress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len);
+int bfq_stream_decompress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len);
+/* device-resident form (input and output in device memory): bfq_stream_reserve(len) sizes the workspace once */
+int bfq_stream_reserve(bfq_ctx *c, uint64_t len);
+int bfq_stream_compress_device(bfq_ctx *c, const uint8_t *d_in, uint64_t len, uint8_t *d_out, uint64_t cap, uint64_t *out_len);
+
 /* ---- profiling: per-kernel HIP-event times accumulated over the calls since
  * the last bfq_prof_reset() (events recorded on bfq_stream()). */
 int  bfq_prof_enable(bfq_ctx *c, int on);

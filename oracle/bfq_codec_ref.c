@@ -1,0 +1,228 @@
+/* bfq_codec_ref.c -- CPU statement of the stream codec (the entropy-coding back end that takes the
+ * place of step 5, BFQzip.py:253-275: `7z a -mm=PPMd OUT.fq.dna.7z OUT.fq.dna`, `bsc e OUT.fq.qs OUT.fq.qs.bsc -T`).
+ * TEST INFRASTRUCTURE ONLY: tests/ compare the GPU codec (bfqzip_amd/csrc/k_codec.hip) with this file byte for byte.
+ *
+ * PARITY UNPINNED against the reference's tools: 7z and libbsc are external (libbsc an empty submodule, 7z a system
+ * binary); neither their sources nor their outputs are in /root/reference.  The container below is this project's own,
+ * chosen for the GPU: a static order-k model per stream + range-ANS (Duda's rANS, byte-wise renormalisation), every
+ * segment of 8192 symbols coded on its own so that encoder and decoder run one segment per lane.
+ *
+ * Container (little endian):
+ *   char  magic[8] = "BFQRANS1"
+ *   u64   raw_len
+ *   u32   seg_syms (8192), nseg = ceil(raw_len / seg_syms), A (distinct byte values), k (context order), scale_bits (12)
+ *   u8    alphabet[256]          byte value of symbol 0..A-1, ascending; the rest 0
+ *   u8    used[ceil(A^k / 8)]    bit c: context c occurs
+ *   u16   freq[used contexts][A] in ascending context order, every row sums to 2^scale_bits
+ *   u32   seg_bytes[nseg]
+ *   u8    payload[]              the segments' rANS streams back to back
+ * Context of a symbol = the k symbols before it INSIDE its segment (missing ones count as symbol 0), read as a base-A
+ * number, oldest symbol most significant.  k = the largest order with A^(k+1) <= min(2^22, max(4096, raw_len / 16)), at most 8.
+ * Model row of a context: f[s] = max(1, floor(count[s] * 2^scale / total)) for count[s] > 0; a surplus over 2^scale is taken
+ * from the largest entries (lowest symbol first among equals, never below 1), a deficit goes to the largest entry.
+ * rANS: state x in [2^23, 2^31), symbols coded last to first, bytes emitted low byte first and stored backwards, so the
+ * decoder reads forwards: x = le32, then per symbol slot = x & (2^scale - 1), s = symbol with cum[s] <= slot < cum[s] + f[s],
+ * x = f[s] * (x >> scale) + slot - cum[s], while x < 2^23: x = x << 8 | next byte.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define BQC_SEG 8192u
+#define BQC_SCALE 12u
+#define BQC_L (1u << 23)
+
+static void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(v >> 8); p[2] = (uint8_t)(v >> 16); p[3] = (uint8_t)(v >> 24); }
+static void put64(uint8_t *p, uint64_t v) { put32(p, (uint32_t)v); put32(p + 4, (uint32_t)(v >> 32)); }
+static uint32_t get32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint64_t get64(const uint8_t *p) { return (uint64_t)get32(p) | ((uint64_t)get32(p + 4) << 32); }
+
+static uint32_t choose_k(uint32_t A, uint64_t n)
+{
+    uint64_t limit = n >> 4;
+    if (limit < 4096) limit = 4096;
+    if (limit > (1u << 22)) limit = 1u << 22;
+    uint32_t k = 0;
+    uint64_t p = (uint64_t)A * A;                   /* A^(k+2) */
+    while (k < 8 && p <= limit) { k++; p *= A; }
+    return k;
+}
+
+static void normalise(const uint32_t *cnt, uint32_t A, uint16_t *f)
+{
+    const uint32_t M = 1u << BQC_SCALE;
+    uint64_t T = 0;
+    for (uint32_t s = 0; s < A; s++) T += cnt[s];
+    uint32_t sum = 0;
+    for (uint32_t s = 0; s < A; s++) {
+        uint32_t v = 0;
+        if (cnt[s]) { v = (uint32_t)(((uint64_t)cnt[s] * M) / T); if (v == 0) v = 1; }
+        f[s] = (uint16_t)v; sum += v;
+    }
+    while (sum > M) {
+        uint32_t best = 0;
+        for (uint32_t s = 1; s < A; s++) if (f[s] > f[best]) best = s;
+        uint32_t d = sum - M;
+        if (d > (uint32_t)f[best] - 1u) d = (uint32_t)f[best] - 1u;
+        f[best] = (uint16_t)(f[best] - d); sum -= d;
+    }
+    if (sum < M) {
+        uint32_t best = 0;
+        for (uint32_t s = 1; s < A; s++) if (f[s] > f[best]) best = s;
+        f[best] = (uint16_t)(f[best] + (M - sum));
+    }
+}
+
+/* returns the container's length, -1 when `cap` is too small, -2 on allocation failure */
+int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap)
+{
+    uint32_t present[256] = {0}, map[256] = {0};
+    for (uint64_t i = 0; i < n; i++) present[in[i]] = 1;
+    uint8_t alphabet[256] = {0};
+    uint32_t A = 0;
+    for (uint32_t b = 0; b < 256; b++) if (present[b]) { map[b] = A; alphabet[A++] = (uint8_t)b; }
+    if (A == 0) A = 1;                                  /* empty input: one dummy symbol */
+    const uint32_t k = choose_k(A, n);
+    uint64_t nctx = 1;
+    for (uint32_t j = 0; j < k; j++) nctx *= A;
+    const uint64_t top = nctx;                          /* A^k: weight of the symbol that leaves the context */
+    const uint32_t nseg = (uint32_t)((n + BQC_SEG - 1) / BQC_SEG);
+    uint32_t *cnt = (uint32_t *)calloc(nctx * A, 4);
+    uint16_t *freq = (uint16_t *)calloc(nctx * A, 2), *cum = (uint16_t *)calloc(nctx * A, 2);
+    uint8_t *tmp = (uint8_t *)malloc(2 * BQC_SEG + 16);
+    if (!cnt || !freq || !cum || !tmp) { free(cnt); free(freq); free(cum); free(tmp); return -2; }
+    for (uint32_t g = 0; g < nseg; g++) {
+        const uint64_t b = (uint64_t)g * BQC_SEG, e = (b + BQC_SEG < n) ? b + BQC_SEG : n;
+        uint64_t ctx = 0;
+        for (uint64_t i = b; i < e; i++) {
+            const uint32_t s = map[in[i]];
+            cnt[ctx * A + s]++;
+            const uint32_t outgoing = (k && i >= b + k) ? map[in[i - k]] : 0;
+            ctx = k ? ctx * A + s - (uint64_t)outgoing * top : 0;
+        }
+    }
+    uint64_t nused = 0;
+    for (uint64_t c = 0; c < nctx; c++) {
+        uint64_t T = 0;
+        for (uint32_t s = 0; s < A; s++) T += cnt[c * A + s];
+        if (!T) continue;
+        nused++;
+        normalise(cnt + c * A, A, freq + c * A);
+        uint32_t acc = 0;
+        for (uint32_t s = 0; s < A; s++) { cum[c * A + s] = (uint16_t)acc; acc += freq[c * A + s]; }
+    }
+    const uint64_t hdr = 8 + 8 + 5 * 4 + 256 + (nctx + 7) / 8 + nused * A * 2 + (uint64_t)nseg * 4;
+    int64_t ret = -1;
+    if (hdr <= cap) {
+        uint8_t *p = out;
+        memcpy(p, "BFQRANS1", 8); p += 8;
+        put64(p, n); p += 8;
+        put32(p, BQC_SEG); put32(p + 4, nseg); put32(p + 8, A); put32(p + 12, k); put32(p + 16, BQC_SCALE); p += 20;
+        memcpy(p, alphabet, 256); p += 256;
+        memset(p, 0, (nctx + 7) / 8);
+        uint8_t *rows = p + (nctx + 7) / 8;
+        for (uint64_t c = 0; c < nctx; c++) {
+            uint64_t T = 0;
+            for (uint32_t s = 0; s < A; s++) T += freq[c * A + s];
+            if (!T) continue;
+            p[c >> 3] |= (uint8_t)(1u << (c & 7));
+            for (uint32_t s = 0; s < A; s++) { rows[0] = (uint8_t)freq[c * A + s]; rows[1] = (uint8_t)(freq[c * A + s] >> 8); rows += 2; }
+        }
+        uint8_t *segtab = rows, *pay = rows + (uint64_t)nseg * 4;
+        uint64_t used = hdr;
+        ret = 0;
+        for (uint32_t g = 0; g < nseg && ret == 0; g++) {
+            const uint64_t b = (uint64_t)g * BQC_SEG, e = (b + BQC_SEG < n) ? b + BQC_SEG : n;
+            /* context in front of the last symbol: the k symbols before it, inside the segment */
+            uint64_t ctx = 0;
+            const uint64_t len = e - b;
+            for (uint64_t i = (len - 1 > k ? e - 1 - k : b); i + 1 < e; i++) ctx = k ? (ctx * A + map[in[i]]) % top : 0;
+            uint8_t *q = tmp + 2 * BQC_SEG + 16;
+            uint32_t x = BQC_L;
+            for (uint64_t i = e; i-- > b;) {
+                const uint32_t s = map[in[i]];
+                const uint32_t f = freq[ctx * A + s], c0 = cum[ctx * A + s];
+                const uint32_t xmax = ((BQC_L >> BQC_SCALE) << 8) * f;
+                while (x >= xmax) { *--q = (uint8_t)x; x >>= 8; }
+                x = ((x / f) << BQC_SCALE) + (x % f) + c0;
+                if (k && i > b) {                                   /* context in front of symbol i-1 */
+                    const uint32_t prev = map[in[i - 1]];
+                    const uint32_t incoming = (i - 1 >= b + k) ? map[in[i - 1 - k]] : 0;
+                    ctx = (ctx + (uint64_t)incoming * top - prev) / A;
+                }
+            }
+            q -= 4; put32(q, x);
+            const uint64_t bytes = (uint64_t)(tmp + 2 * BQC_SEG + 16 - q);
+            if (used + bytes > cap) { ret = -1; break; }
+            memcpy(pay, q, bytes); pay += bytes; used += bytes;
+            put32(segtab + 4ull * g, (uint32_t)bytes);
+        }
+        if (ret == 0) ret = (int64_t)used;
+    }
+    free(cnt); free(freq); free(cum); free(tmp);
+    return ret;
+}
+
+/* raw length of a container (-1: not one) */
+int64_t orc_codec_raw_len(const uint8_t *in, uint64_t len)
+{
+    if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
+    return (int64_t)get64(in + 8);
+}
+
+/* returns raw_len, -1 on a malformed container / short `cap` */
+int64_t orc_codec_decode(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t cap)
+{
+    if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
+    const uint64_t n = get64(in + 8);
+    const uint32_t seg = get32(in + 16), nseg = get32(in + 20), A = get32(in + 24), k = get32(in + 28), scale = get32(in + 32);
+    if (n > cap || seg != BQC_SEG || scale != BQC_SCALE || A == 0 || A > 256 || k > 8 || nseg != (n + seg - 1) / seg) return -1;
+    const uint8_t *alphabet = in + 36;
+    uint64_t nctx = 1;
+    for (uint32_t j = 0; j < k; j++) { nctx *= A; if (nctx > (1u << 22)) return -1; }
+    const uint64_t top = nctx;
+    const uint8_t *used = in + 36 + 256;
+    if (36 + 256 + (nctx + 7) / 8 > len) return -1;
+    const uint8_t *rows = used + (nctx + 7) / 8;
+    uint16_t *freq = (uint16_t *)calloc(nctx * A, 2), *cum = (uint16_t *)calloc(nctx * A, 2);
+    if (!freq || !cum) { free(freq); free(cum); return -1; }
+    int64_t ret = (int64_t)n;
+    for (uint64_t c = 0; c < nctx && ret >= 0; c++) {
+        if (!((used[c >> 3] >> (c & 7)) & 1)) continue;
+        if ((uint64_t)(rows - in) + 2ull * A > len) { ret = -1; break; }
+        uint32_t acc = 0;
+        for (uint32_t s = 0; s < A; s++) { freq[c * A + s] = (uint16_t)(rows[0] | (rows[1] << 8)); rows += 2; cum[c * A + s] = (uint16_t)acc; acc += freq[c * A + s]; }
+        if (acc != (1u << scale)) ret = -1;
+    }
+    const uint8_t *segtab = rows;
+    if (ret >= 0 && (uint64_t)(segtab - in) + 4ull * nseg > len) ret = -1;
+    const uint8_t *pay = segtab + 4ull * nseg;
+    for (uint32_t g = 0; g < nseg && ret >= 0; g++) {
+        const uint64_t bytes = get32(segtab + 4ull * g);
+        if (bytes < 4 || (uint64_t)(pay - in) + bytes > len) { ret = -1; break; }
+        const uint8_t *q = pay, *qe = pay + bytes;
+        uint32_t x = get32(q); q += 4;
+        const uint64_t b = (uint64_t)g * seg, e = (b + seg < n) ? b + seg : n;
+        uint64_t ctx = 0;
+        uint32_t hist[8] = {0};
+        for (uint64_t i = b; i < e; i++) {
+            const uint32_t slot = x & ((1u << scale) - 1);
+            const uint16_t *fr = freq + ctx * A, *cu = cum + ctx * A;
+            uint32_t s = 0;
+            while (s < A && !(fr[s] && slot < (uint32_t)cu[s] + fr[s])) s++;       /* the rows partition [0, 2^scale) */
+            if (s == A) { ret = -1; break; }
+            x = fr[s] * (x >> scale) + slot - cu[s];
+            while (x < BQC_L) { if (q >= qe) { ret = -1; break; } x = (x << 8) | *q++; }
+            if (ret < 0) break;
+            out[i] = alphabet[s];
+            if (k) {
+                const uint32_t outgoing = (i >= b + k) ? hist[(i - b) % k] : 0;
+                hist[(i - b) % k] = s;
+                ctx = ctx * A + s - (uint64_t)outgoing * top;
+            }
+        }
+        pay += bytes;
+    }
+    free(freq); free(cum);
+    return ret;
+}

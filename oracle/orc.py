@@ -98,3 +98,31 @@ def ref_binary(M, B):
     """Path of the compiled REFERENCE bfq_int for (M,B), or None if not built."""
     p = os.path.join(_HERE, "_ref", f"bfq_int_M{M}_B{B}")
     return p if os.path.exists(p) else None
+
+
+# ---- stream codec (oracle/bfq_codec_ref.c): the CPU statement of the BFQRANS1 container
+def codec_encode(data):
+    data = np.ascontiguousarray(np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data, np.uint8)
+    L = lib()
+    L.orc_codec_encode.restype = C.c_int64
+    cap = 2 * len(data) + (12 << 20)
+    out = np.empty(cap, np.uint8)
+    r = L.orc_codec_encode(_p(data), C.c_uint64(len(data)), _p(out), C.c_uint64(cap))
+    if r < 0:
+        raise RuntimeError("orc_codec_encode failed: %d" % r)
+    return out[:r].copy()
+
+
+def codec_decode(blob):
+    blob = np.ascontiguousarray(blob, np.uint8)
+    L = lib()
+    L.orc_codec_decode.restype = C.c_int64
+    L.orc_codec_raw_len.restype = C.c_int64
+    n = L.orc_codec_raw_len(_p(blob), C.c_uint64(len(blob)))
+    if n < 0:
+        raise RuntimeError("not a BFQRANS1 stream")
+    out = np.empty(max(int(n), 1), np.uint8)
+    r = L.orc_codec_decode(_p(blob), C.c_uint64(len(blob)), _p(out), C.c_uint64(n))
+    if r != n:
+        raise RuntimeError("orc_codec_decode failed: %d" % r)
+    return out[:n]

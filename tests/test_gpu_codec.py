@@ -1,0 +1,95 @@
+"""GPU stream codec (bfqzip_amd/csrc/k_codec.hip, SURVEY 8(f).4: the entropy coder that takes the place of step 5,
+BFQzip.py:253-275) against its CPU statement oracle/bfq_codec_ref.c: the container must be the same bytes, the decoder
+must return the input, on the output streams of the pipeline itself and on the shapes of tests/codec_cases.py.
+Parity with 7z PPMd / libbsc is unpinned (external tools, not in the reference tree): the container is this project's own."""
+import os, subprocess
+import numpy as np
+import pytest
+from bfqzip_amd import api
+from oracle import orc
+from tests import util
+from tests.codec_cases import cases
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name", sorted(cases().keys()))
+def test_container_equals_cpu_statement(engine, name):
+    data = cases()[name]
+    blob = engine.stream_compress(data)
+    want = orc.codec_encode(data)
+    assert len(blob) == len(want) and (np.asarray(blob) == want).all()
+    back = engine.stream_decompress(blob)
+    assert len(back) == len(data) and (np.asarray(back) == data).all()
+    assert (orc.codec_decode(np.asarray(blob)) == data).all()
+
+
+def test_pipeline_streams(engine):
+    """OUT.fq.dna / OUT.fq.qs / OUT.h of a 200 k x 100 synthetic run (M=2, --m3 with headers): the smoothed quality stream
+    must shrink far below the DNA stream, everything must come back."""
+    sp = api.synth_spec(200000, 100, seed=7)
+    text = np.empty(200000 * 260, np.uint8)
+    n = engine.synth_fastq(sp, text)
+    engine.set_params(m=5)
+    r = engine.fastq_job([text[:n]], keep_headers=True, fastq=False, streams=True, hdr=True)
+    sizes = {}
+    for key, raw in (("dna", r.dna), ("qs", r.qs), ("hdr", r.hdr)):
+        raw = np.asarray(raw)
+        blob = engine.stream_compress(raw)
+        assert (np.asarray(engine.stream_decompress(blob)) == raw).all()
+        want = orc.codec_encode(raw)
+        assert len(blob) == len(want) and (np.asarray(blob) == want).all()
+        sizes[key] = (len(raw), len(blob))
+    assert sizes["qs"][1] < 0.25 * sizes["qs"][0]            # smoothed qualities: well under 2 bits per value
+    assert sizes["dna"][1] < 0.30 * sizes["dna"][0]           # bases: about 2 bits each
+    assert sizes["hdr"][1] < 0.35 * sizes["hdr"][0]
+
+
+def test_large_stream_round_trip(engine):
+    """More segments than one launch has lanes, a model table near its largest size (6 symbols, order 6)."""
+    rng = np.random.default_rng(5)
+    g = rng.choice(np.frombuffer(b"ACGT", np.uint8), 2_000_000)
+    starts = rng.integers(0, len(g) - 150, 400000)
+    lines = np.empty((len(starts), 151), np.uint8)
+    lines[:, :150] = g[starts[:, None] + np.arange(150)[None, :]]
+    lines[:, 150] = 10
+    raw = lines.reshape(-1)
+    raw[rng.integers(0, len(raw), 5000)] = ord("N")           # 6 symbols (the newline may be hit: any bytes compress)
+    blob = engine.stream_compress(raw)
+    assert (np.asarray(engine.stream_decompress(blob)) == raw).all()
+    assert len(blob) < 0.27 * len(raw)
+
+
+def test_refuses_damaged_streams(engine):
+    blob = np.asarray(engine.stream_compress(cases()["dna_like"])).copy()
+    with pytest.raises(api.BfqError):
+        engine.stream_decompress(blob[:len(blob) // 2])
+    bad = blob.copy(); bad[3] ^= 0x20
+    with pytest.raises(api.BfqError):
+        engine.stream_decompress(bad)
+    flip = blob.copy(); flip[-5] ^= 0xFF                       # payload damage: wrong bytes or a refused stream, never a hang
+    try:
+        engine.stream_decompress(flip)
+    except api.BfqError:
+        pass
+
+
+def test_bsc_front_end(tmp_path):
+    """`external/libbsc/bsc e F F.bsc -T` as BFQzip.py:265-275 runs it, and `bsc d` back."""
+    exe = os.path.join(ROOT, "dropin", "external", "libbsc", "bsc")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "bfqzip_amd", "csrc"), "cli"])
+    raw = cases()["runs_20_symbols"].tobytes()
+    f = tmp_path / "OUT.fq.qs"
+    f.write_bytes(raw)
+    r = subprocess.run([exe, "e", str(f), str(f) + ".bsc", "-T"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout
+    blob = (tmp_path / "OUT.fq.qs.bsc").read_bytes()
+    assert blob[:8] == b"BFQRANS1" and len(blob) < len(raw) // 3
+    assert (orc.codec_encode(np.frombuffer(raw, np.uint8)) == np.frombuffer(blob, np.uint8)).all()
+    r = subprocess.run([exe, "d", str(f) + ".bsc", str(tmp_path / "back")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert (tmp_path / "back").read_bytes() == raw
+    r = subprocess.run([exe, "d", str(f), str(tmp_path / "x")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode != 0
