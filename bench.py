@@ -127,6 +127,57 @@ def e2e_host(api, eng, sp, N, L, iters, log):
     return out, pin, tlen, outs
 
 
+def stream_codec(api, eng, outs, lens, N, L, log, with_cpu):
+    """the step the reference hands to 7z / bsc (BFQzip.py:253-275) -- the three output streams of the run
+    above through the GPU codec (bfq_stream_compress: pinned host buffer in, pinned host buffer out), sizes and wall time;
+    with_cpu: bzip2 -9 / xz -2 on the first 32 MB of each stream beside it (the reference's own tools are not in its tree)."""
+    import subprocess, tempfile
+    res = {}
+    cap = eng.stream_bound(max(lens.values()))
+    pout = api.PinnedBuffer(cap)
+    pback = api.PinnedBuffer(max(lens.values()) + 64)
+    tot_raw = tot_cmp = 0
+    tot_t = 0.0
+    for k in ("dna", "qs", "hdr"):
+        raw = outs[k].array[:lens[k]]
+        eng.stream_compress(raw, out=pout.array)                 # warm-up: sizes the workspace
+        eng.prof_reset()
+        t0 = time.perf_counter()
+        blob = eng.stream_compress(raw, out=pout.array)
+        dt = time.perf_counter() - t0
+        pr = eng.prof()
+        t1 = time.perf_counter()
+        back = eng.stream_decompress(blob, out=pback.array)
+        dt2 = time.perf_counter() - t1
+        ok = bool(len(back) == len(raw) and np.array_equal(back[:1 << 24], raw[:1 << 24]) and np.array_equal(back[-(1 << 24):], raw[-(1 << 24):]))
+        res[k] = {"raw_bytes": int(len(raw)), "compressed_bytes": int(len(blob)), "bits_per_symbol": round(8.0 * len(blob) / max(len(raw), 1), 4),
+                  "compress_wall_ms": round(dt * 1e3, 1), "decompress_wall_ms": round(dt2 * 1e3, 1), "round_trip_ok": ok,
+                  "kernel_ms": round(pr.get("k_codec", {}).get("ms", 0.0), 1)}
+        tot_raw += len(raw); tot_cmp += len(blob); tot_t += dt
+        log(f"stream_codec {k}: {len(raw)} -> {len(blob)} bytes, {dt * 1e3:.0f} ms")
+        if with_cpu:
+            n = min(len(raw), 32 << 20)
+            with tempfile.NamedTemporaryFile(dir="/dev/shm", delete=False) as f:
+                f.write(raw[:n].tobytes())
+            try:
+                ref = {}
+                for tool, cmd in (("bzip2 -9", ["bzip2", "-9", "-c", f.name]), ("xz -2", ["xz", "-2", "-T1", "-c", f.name])):
+                    t0 = time.perf_counter()
+                    o = subprocess.run(cmd, stdout=subprocess.PIPE, check=True).stdout
+                    ref[tool] = {"bits_per_symbol": round(8.0 * len(o) / n, 4), "MB_per_s_1_core": round(n / 1e6 / (time.perf_counter() - t0), 1)}
+                ours = eng.stream_compress(raw[:n])
+                ref["this codec, same sample"] = {"bits_per_symbol": round(8.0 * len(ours) / n, 4)}
+                res[k]["cpu_tools_32MB_sample"] = ref
+            finally:
+                os.unlink(f.name)
+    pout.free(); pback.free()
+    res["total"] = {"raw_bytes": int(tot_raw), "compressed_bytes": int(tot_cmp), "ratio": round(tot_raw / max(tot_cmp, 1), 2),
+                    "compress_GB_per_s_host_to_host": round(tot_raw / 1e9 / tot_t, 2)}
+    res["what"] = ("OUT.fq.dna / OUT.fq.qs / OUT.h of the e2e_host run -> bfq_stream_compress (BFQRANS1: static order-k model + rANS, "
+                   "8192-symbol segments, one lane per segment) -> bfq_stream_decompress; container = oracle/bfq_codec_ref.c byte for byte")
+    return res
+
+
 def ebwt_modes(api, eng, text, N, L, log):
     """The reference's tool boundary in process, host arrays (pinned) in and out: step 1 alone (gsufsort / eGap: FASTQ text ->
     eBWT, QS, LCP), then steps 2-4 on that eBWT in bfq_int mode (LCP deduced from the BWT alone, k_bfs.hip) and in bfq_ext
@@ -375,6 +426,13 @@ def main():
                     res["e2e_host"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_e2e and text is not None and "error" not in res.get("e2e_host", {}):
                 res["global_mode"] = global_mode(api, parallel, eng, text, Nw, L, outs["dna"].array[:Nw * (L + 1)], outs["qs"].array[:Nw * (L + 1)], log)
+            if not args.no_e2e and text is not None and "error" not in res.get("e2e_host", {}):
+                try:
+                    nl = Nw * (L + 1)
+                    lens = {"dna": nl, "qs": nl, "hdr": res["e2e_host"]["bytes_out"] - 2 * nl}
+                    res["stream_codec"] = stream_codec(api, eng, outs, lens, Nw, L, log, not args.no_cpu)
+                except Exception as e:
+                    res["stream_codec"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_e2e:
                 try:
                     for v in outs.values():

@@ -19,7 +19,7 @@
 const char *const BFQ_KERNEL_NAMES[K_NUM] = {
     "k_text_from_reads", "k_pack3", "k_build_keys", "k_radix_hist", "k_scan", "k_radix_scatter", "k_huge_round",
     "k_cluster_big", "k_refine_chunk", "k_refine_big", "k_emit_bwt", "k_lf_count", "k_lf_build", "k_lcp_flags",
-    "k_cluster", "k_invert_count", "k_invert", "k_synth", "k_fastq", "k_bfs", "misc"};
+    "k_cluster", "k_invert_count", "k_invert", "k_synth", "k_fastq", "k_bfs", "k_codec", "misc"};
 
 static thread_local std::string g_createErr;
 

@@ -25,7 +25,7 @@ struct BfqError {
 enum BfqKernel {
     K_TEXT = 0, K_PACK, K_KEYS, K_RADIX_HIST, K_SCAN, K_RADIX_SCATTER, K_HUGE_ROUND, K_CLUSTER_BIG,
     K_REFINE_WAVE, K_REFINE_BIG, K_EMIT, K_RANK_BUILD, K_RANK_FINAL, K_LCP_FLAGS, K_CLUSTER,
-    K_INVERT_COUNT, K_INVERT, K_SYNTH, K_FASTQ, K_BFS, K_MISC, K_NUM
+    K_INVERT_COUNT, K_INVERT, K_SYNTH, K_FASTQ, K_BFS, K_CODEC, K_MISC, K_NUM
 };
 extern const char *const BFQ_KERNEL_NAMES[K_NUM];
 

@@ -6,7 +6,10 @@
 // the tests compare this file with, byte for byte.
 //
 //   k_cdc_present : which byte values occur                                  (alphabet, dense symbol numbers)
-//   k_cdc_count   : occurrences of every (context, symbol) pair; a lane walks its segment forwards and adds up
+//   k_cdc_count   : occurrences of every (context, symbol) pair in a SAMPLE of the segments (every S-th, S <= 64: a
+//                   histogram of all symbols into millions of bins is atomics-bound, 47-170 ms per 0.9 G symbols, and
+//                   the model does not need it -- every symbol keeps a non-zero share in every row and contexts
+//                   the sample misses use the order-0 row); a lane walks its segment forwards and adds up
 //                   runs of equal pairs before it touches the table (smoothed quality streams are long runs:
 //                   one atomic per run, not per symbol)
 //   host          : k, the model rows (normalised to 2^12), the cumulative rows -- the table is at most 4 M entries
@@ -19,10 +22,10 @@
 #include "bfq_internal.h"
 #include "bfq_device.h"
 
-#define CQ_SEG 8192u
+#define CQ_SEG_MAX 8192u                             // symbols per segment; halved down to 1024 for short streams (cdc_choose_seg)
 #define CQ_SCALE 12u
 #define CQ_L (1u << 23)
-#define CQ_SLOT (2u * CQ_SEG + 16u)                  // scratch bytes per segment (a symbol costs at most 12 bits)
+#define CQ_SLOT(seg) (2u * (seg) + 16u)              // scratch bytes per segment (a symbol costs at most 12 bits)
 #define CQ_MAX_TABLE (1u << 22)
 
 __global__ __launch_bounds__(256) void k_cdc_present(const u8 *__restrict__ in, u64 n, u32 *__restrict__ present)
@@ -36,7 +39,7 @@ __global__ __launch_bounds__(256) void k_cdc_present(const u8 *__restrict__ in, 
 }
 
 struct CdcModel {
-    u32 A, k, nseg;
+    u32 A, k, nseg, seg;
     u32 top;                 // A^k
     u64 n;
 };
@@ -50,25 +53,43 @@ __device__ __forceinline__ u32 cdc_next_ctx(u32 ctx, u32 s, u64 &win, const CdcM
     return ctx * m.A + s - outgoing * m.top;
 }
 
+// Hot (context, symbol) pairs -- a header stream has a few dozen, a smoothed quality stream a handful -- would serialise on
+// their table entries (77 M atomics on such keys took 70 ms).  Every workgroup therefore owns a direct-mapped cache of 4096
+// pairs in LDS: the first pair to claim a slot counts there (LDS atomics), everything else goes to the table; the caches
+// are added to the table when the workgroup is done.  The sums are exact either way.
+#define CQ_CACHE 4096u
+__device__ __forceinline__ void cdc_add(u32 *tag, u32 *cnt, u32 *__restrict__ gcnt, u32 key, u32 v)
+{
+    const u32 slot = key & (CQ_CACHE - 1u);
+    u32 t = tag[slot];
+    if (t == 0xFFFFFFFFu) { const u32 old = atomicCAS(&tag[slot], 0xFFFFFFFFu, key); t = (old == 0xFFFFFFFFu) ? key : old; }
+    if (t == key) atomicAdd(&cnt[slot], v);
+    else atomicAdd(&gcnt[key], v);
+}
 __global__ __launch_bounds__(256) void k_cdc_count(const u8 *__restrict__ in, const u8 *__restrict__ map, CdcModel m,
-                                                   u32 *__restrict__ cnt)
+                                                   u32 step, u32 *__restrict__ cnt)
 {
     __shared__ u8 smap[256];
+    __shared__ u32 ctag[CQ_CACHE], ccnt[CQ_CACHE];
     smap[threadIdx.x] = map[threadIdx.x];
+    for (u32 j = threadIdx.x; j < CQ_CACHE; j += 256) { ctag[j] = 0xFFFFFFFFu; ccnt[j] = 0; }
     __syncthreads();
-    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < m.nseg; g += (u64)gridDim.x * blockDim.x) {
-        const u64 b = g * CQ_SEG, e = (b + CQ_SEG < m.n) ? b + CQ_SEG : m.n;
+    for (u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * step; g < m.nseg; g += (u64)gridDim.x * blockDim.x * step) {
+        const u64 b = g * m.seg, e = (b + m.seg < m.n) ? b + m.seg : m.n;
         u32 ctx = 0, lastKey = 0xFFFFFFFFu, run = 0;
         u64 win = 0;
         for (u64 i = b; i < e; i++) {
             const u32 s = smap[in[i]];
             const u32 key = ctx * m.A + s;
             if (key == lastKey) run++;
-            else { if (run) atomicAdd(&cnt[lastKey], run); lastKey = key; run = 1; }
+            else { if (run) cdc_add(ctag, ccnt, cnt, lastKey, run); lastKey = key; run = 1; }
             ctx = cdc_next_ctx(ctx, s, win, m);
         }
-        if (run) atomicAdd(&cnt[lastKey], run);
+        if (run) cdc_add(ctag, ccnt, cnt, lastKey, run);
     }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < CQ_CACHE; j += 256)
+        if (ccnt[j]) atomicAdd(&cnt[ctag[j]], ccnt[j]);
 }
 
 __global__ __launch_bounds__(256) void k_cdc_encode(const u8 *__restrict__ in, const u8 *__restrict__ map, CdcModel m,
@@ -79,14 +100,14 @@ __global__ __launch_bounds__(256) void k_cdc_encode(const u8 *__restrict__ in, c
     smap[threadIdx.x] = map[threadIdx.x];
     __syncthreads();
     for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < m.nseg; g += (u64)gridDim.x * blockDim.x) {
-        const u64 b = g * CQ_SEG, e = (b + CQ_SEG < m.n) ? b + CQ_SEG : m.n;
+        const u64 b = g * m.seg, e = (b + m.seg < m.n) ? b + m.seg : m.n;
         // context in front of the last symbol
         u32 ctx = 0;
         if (m.k) {
             const u64 len = e - b;
             for (u64 i = (len - 1 > m.k ? e - 1 - m.k : b); i + 1 < e; i++) ctx = (ctx * m.A + smap[in[i]]) % m.top;
         }
-        u8 *const slotEnd = scratch + (g + 1) * (u64)CQ_SLOT;
+        u8 *const slotEnd = scratch + (g + 1) * (u64)CQ_SLOT(m.seg);
         u8 *q = slotEnd;
         u32 x = CQ_L;
         u32 s = smap[in[e - 1]];
@@ -112,13 +133,13 @@ __global__ __launch_bounds__(256) void k_cdc_encode(const u8 *__restrict__ in, c
 
 // one wavefront per segment: its stream from the end of its scratch slot to its place in the output
 __global__ __launch_bounds__(256) void k_cdc_pack(const u8 *__restrict__ scratch, const u32 *__restrict__ segBytes,
-                                                  const u64 *__restrict__ off, u32 nseg, u8 *__restrict__ out)
+                                                  const u64 *__restrict__ off, u32 nseg, u32 seg, u8 *__restrict__ out)
 {
     const u32 lane = bfq_lane();
     const u64 nwaves = ((u64)gridDim.x * blockDim.x) >> 6;
     for (u64 g = ((u64)blockIdx.x * blockDim.x + threadIdx.x) >> 6; g < nseg; g += nwaves) {
         const u32 bytes = segBytes[g];
-        const u8 *src = scratch + (g + 1) * (u64)CQ_SLOT - bytes;
+        const u8 *src = scratch + (g + 1) * (u64)CQ_SLOT(seg) - bytes;
         u8 *dst = out + off[g];
         for (u32 j = lane; j < bytes; j += 64) dst[j] = src[j];
     }
@@ -136,7 +157,7 @@ __global__ __launch_bounds__(256) void k_cdc_decode(const u8 *__restrict__ pay, 
         const u8 *q = pay + off[g], *const qe = q + segBytes[g];
         u32 x = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
         q += 4;
-        const u64 b = g * CQ_SEG, e = (b + CQ_SEG < m.n) ? b + CQ_SEG : m.n;
+        const u64 b = g * m.seg, e = (b + m.seg < m.n) ? b + m.seg : m.n;
         u32 ctx = 0;
         u64 win = 0;
         bool ok = true;
@@ -181,8 +202,8 @@ static void cdc_normalise(const u32 *cnt, u32 A, u16 *f)
     for (u32 s = 0; s < A; s++) T += cnt[s];
     u32 sum = 0;
     for (u32 s = 0; s < A; s++) {
-        u32 v = 0;
-        if (cnt[s]) { v = (u32)(((u64)cnt[s] * M) / T); if (v == 0) v = 1; }
+        u32 v = T ? (u32)(((u64)cnt[s] * M) / T) : 0;
+        if (v == 0) v = 1;                                        // every symbol of the alphabet can be coded in every context
         f[s] = (u16)v; sum += v;
     }
     while (sum > M) {
@@ -198,6 +219,17 @@ static void cdc_normalise(const u32 *cnt, u32 A, u16 *f)
         f[best] = (u16)(f[best] + (M - sum));
     }
 }
+static u32 cdc_choose_seg(u64 n)
+{
+    u32 seg = CQ_SEG_MAX;
+    while (seg > 1024 && n / seg < 65536) seg >>= 1;
+    return seg;
+}
+static u32 cdc_sample_step(u64 n)
+{
+    const u64 S = n >> 24;                                        // at least 16 M symbols are counted (all of a shorter stream)
+    return S < 1 ? 1u : (S > 64 ? 64u : (u32)S);
+}
 static void put32(u8 *p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); p[3] = (u8)(v >> 24); }
 static void put64(u8 *p, u64 v) { put32(p, (u32)v); put32(p + 4, (u32)(v >> 32)); }
 static u32 get32(const u8 *p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); }
@@ -206,14 +238,14 @@ static u64 get64(const u8 *p) { return (u64)get32(p) | ((u64)get32(p + 4) << 32)
 // upper bound of a container for n raw bytes (what callers size their output buffers with)
 u64 bfq_codec_bound(u64 n)
 {
-    const u64 nseg = (n + CQ_SEG - 1) / CQ_SEG;
-    return 36 + 256 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64;
+    const u64 nseg = (n + 1023) / 1024;
+    return 36 + 256 + 512 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64;
 }
 // device workspace of one compress / decompress call
 u64 bfq_codec_workspace(u64 n)
 {
-    const u64 nseg = (n + CQ_SEG - 1) / CQ_SEG;
-    return n + bfq_codec_bound(n) + nseg * (u64)CQ_SLOT + 16ull * CQ_MAX_TABLE + 24 * nseg + (64u << 20);
+    const u64 nseg = (n + 1023) / 1024;
+    return n + bfq_codec_bound(n) + nseg * (u64)CQ_SLOT(1024) + 16ull * CQ_MAX_TABLE + 24 * nseg + (64u << 20);
 }
 
 // d_in: n raw bytes on the device.  The container goes to d_out (capacity cap); returns its length.
@@ -222,7 +254,7 @@ u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 
     const size_t mk = c->mark();
     u32 *d_present = c->alloc<u32>(256);
     HIP_CHECK(hipMemsetAsync(d_present, 0, 1024, c->stream));
-    if (n) KLAUNCH(c, K_MISC, (double)n, k_cdc_present, bfq_grid(n, 256 * 64), 256, d_in, n, d_present);
+    if (n) KLAUNCH(c, K_CODEC, (double)n, k_cdc_present, bfq_grid(n, 256 * 64), 256, d_in, n, d_present);
     u32 present[256];
     HIP_CHECK(hipMemcpyAsync(present, d_present, 1024, hipMemcpyDeviceToHost, c->stream));
     c->sync();
@@ -231,7 +263,8 @@ u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 
     for (u32 b = 0; b < 256; b++) if (present[b]) { map[b] = (u8)A; alphabet[A++] = (u8)b; }
     if (A == 0) A = 1;
     CdcModel m;
-    m.A = A; m.k = cdc_choose_k(A, n); m.n = n; m.nseg = (u32)((n + CQ_SEG - 1) / CQ_SEG);
+    const u32 step = cdc_sample_step(n);
+    m.A = A; m.k = cdc_choose_k(A, n / step); m.n = n; m.seg = cdc_choose_seg(n); m.nseg = (u32)((n + m.seg - 1) / m.seg);
     u64 nctx = 1;
     for (u32 j = 0; j < m.k; j++) nctx *= A;
     m.top = (u32)nctx;
@@ -240,51 +273,58 @@ u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 
     HIP_CHECK(hipMemcpyAsync(d_map, map, 256, hipMemcpyHostToDevice, c->stream));
     u32 *d_cnt = c->alloc<u32>(E);
     HIP_CHECK(hipMemsetAsync(d_cnt, 0, 4 * E, c->stream));
-    if (n) KLAUNCH(c, K_MISC, (double)n, k_cdc_count, bfq_grid(m.nseg, 256), 256, d_in, (const u8 *)d_map, m, d_cnt);
+    if (n) KLAUNCH(c, K_CODEC, (double)n / step, k_cdc_count, bfq_grid((m.nseg + step - 1) / step, 256), 256, d_in, (const u8 *)d_map, m, step, d_cnt);
     std::vector<u32> cnt(E);
     HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, 4 * E, hipMemcpyDeviceToHost, c->stream));
     c->sync();
     std::vector<u16> freq(E, 0), cum(E, 0);
     std::vector<u8> used((nctx + 7) / 8, 0);
     u64 nused = 0;
+    u32 cnt0[256] = {0};
+    u16 dflt[256] = {0};
+    for (u64 x = 0; x < nctx; x++)
+        for (u32 s = 0; s < A; s++) { const u64 v = (u64)cnt0[s] + cnt[x * A + s]; cnt0[s] = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)v; }
+    cdc_normalise(cnt0, A, dflt);
     for (u64 x = 0; x < nctx; x++) {
         u64 T = 0;
         for (u32 s = 0; s < A; s++) T += cnt[x * A + s];
-        if (!T) continue;
-        nused++;
-        used[x >> 3] |= (u8)(1u << (x & 7));
-        cdc_normalise(cnt.data() + x * A, A, freq.data() + x * A);
+        if (T) {
+            nused++;
+            used[x >> 3] |= (u8)(1u << (x & 7));
+            cdc_normalise(cnt.data() + x * A, A, freq.data() + x * A);
+        } else memcpy(freq.data() + x * A, dflt, 2 * A);
         u32 acc = 0;
         for (u32 s = 0; s < A; s++) { cum[x * A + s] = (u16)acc; acc += freq[x * A + s]; }
     }
-    const u64 hdr = 36 + 256 + used.size() + nused * A * 2 + 4ull * m.nseg;
+    const u64 hdr = 36 + 256 + 2ull * A + used.size() + nused * A * 2 + 4ull * m.nseg;
     if (hdr > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
     u16 *d_freq = c->alloc<u16>(E), *d_cum = c->alloc<u16>(E);
     HIP_CHECK(hipMemcpyAsync(d_freq, freq.data(), 2 * E, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipMemcpyAsync(d_cum, cum.data(), 2 * E, hipMemcpyHostToDevice, c->stream));
     u32 *d_segBytes = c->alloc<u32>(m.nseg + 1);
     u64 *d_off = c->alloc<u64>(m.nseg + 1), *d_total = c->alloc<u64>(1);
-    u8 *scratch = c->alloc<u8>((u64)m.nseg * CQ_SLOT + 16);
+    u8 *scratch = c->alloc<u8>((u64)m.nseg * CQ_SLOT(m.seg) + 16);
     u64 total = 0;
     std::vector<u32> segBytes(m.nseg);
     if (m.nseg) {
-        KLAUNCH(c, K_MISC, 3.0 * (double)n, k_cdc_encode, bfq_grid(m.nseg, 256), 256, d_in, (const u8 *)d_map, m, (const u16 *)d_freq,
+        KLAUNCH(c, K_CODEC, 3.0 * (double)n, k_cdc_encode, bfq_grid(m.nseg, 256), 256, d_in, (const u8 *)d_map, m, (const u16 *)d_freq,
                 (const u16 *)d_cum, scratch, d_segBytes);
         bfq_exscan_u32(c, d_segBytes, d_off, m.nseg, d_total);
         HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipMemcpyAsync(segBytes.data(), d_segBytes, 4ull * m.nseg, hipMemcpyDeviceToHost, c->stream));
         c->sync();
         if (hdr + total > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
-        KLAUNCH(c, K_MISC, 2.0 * (double)total, k_cdc_pack, bfq_grid((u64)m.nseg * 64, 256), 256, (const u8 *)scratch, (const u32 *)d_segBytes,
-                (const u64 *)d_off, m.nseg, d_out + hdr);
+        KLAUNCH(c, K_CODEC, 2.0 * (double)total, k_cdc_pack, bfq_grid((u64)m.nseg * 64, 256), 256, (const u8 *)scratch, (const u32 *)d_segBytes,
+                (const u64 *)d_off, m.nseg, m.seg, d_out + hdr);
     }
     std::vector<u8> h(hdr);
     u8 *p = h.data();
     memcpy(p, "BFQRANS1", 8); put64(p + 8, n);
-    put32(p + 16, CQ_SEG); put32(p + 20, m.nseg); put32(p + 24, A); put32(p + 28, m.k); put32(p + 32, CQ_SCALE);
+    put32(p + 16, m.seg); put32(p + 20, m.nseg); put32(p + 24, A); put32(p + 28, m.k); put32(p + 32, CQ_SCALE);
     memcpy(p + 36, alphabet, 256);
-    memcpy(p + 36 + 256, used.data(), used.size());
-    u8 *rows = p + 36 + 256 + used.size();
+    for (u32 s = 0; s < A; s++) { p[36 + 256 + 2 * s] = (u8)dflt[s]; p[36 + 256 + 2 * s + 1] = (u8)(dflt[s] >> 8); }
+    memcpy(p + 36 + 256 + 2ull * A, used.data(), used.size());
+    u8 *rows = p + 36 + 256 + 2ull * A + used.size();
     for (u64 x = 0; x < nctx; x++) {
         if (!((used[x >> 3] >> (x & 7)) & 1)) continue;
         for (u32 s = 0; s < A; s++) { rows[0] = (u8)freq[x * A + s]; rows[1] = (u8)(freq[x * A + s] >> 8); rows += 2; }
@@ -306,22 +346,27 @@ static void cdc_parse(const u8 *in, u64 len, CdcHeader &H)
     CdcModel &m = H.m;
     m.n = get64(in + 8);
     const u32 seg = get32(in + 16), scale = get32(in + 32);
+    m.seg = seg;
     m.nseg = get32(in + 20); m.A = get32(in + 24); m.k = get32(in + 28);
-    if (seg != CQ_SEG || scale != CQ_SCALE || m.A == 0 || m.A > 256 || m.k > 8 || m.nseg != (m.n + seg - 1) / seg) throw bad;
+    if (seg != cdc_choose_seg(m.n) || scale != CQ_SCALE || m.A == 0 || m.A > 256 || m.k > 8 || m.nseg != (m.n + seg - 1) / seg) throw bad;
     u64 nctx = 1;
     for (u32 j = 0; j < m.k; j++) { nctx *= m.A; if (nctx > CQ_MAX_TABLE) throw bad; }
     if (nctx * m.A > CQ_MAX_TABLE) throw bad;
     m.top = (u32)nctx;
     H.alphabet.assign(in + 36, in + 36 + 256);
-    const u8 *used = in + 36 + 256;
-    if (36 + 256 + (nctx + 7) / 8 > len) throw bad;
+    if (36 + 256 + 2ull * m.A + (nctx + 7) / 8 > len) throw bad;
+    const u8 *dfl = in + 36 + 256;
+    const u8 *used = dfl + 2ull * m.A;
     const u8 *rows = used + (nctx + 7) / 8;
     H.freq.assign(nctx * m.A, 0); H.cum.assign(nctx * m.A, 0);
     for (u64 x = 0; x < nctx; x++) {
-        if (!((used[x >> 3] >> (x & 7)) & 1)) continue;
-        if ((u64)(rows - in) + 2ull * m.A > len) throw bad;
+        const u8 *row = dfl;
+        if ((used[x >> 3] >> (x & 7)) & 1) {
+            if ((u64)(rows - in) + 2ull * m.A > len) throw bad;
+            row = rows; rows += 2ull * m.A;
+        }
         u32 acc = 0;
-        for (u32 s = 0; s < m.A; s++) { H.freq[x * m.A + s] = (u16)(rows[0] | (rows[1] << 8)); rows += 2; H.cum[x * m.A + s] = (u16)acc; acc += H.freq[x * m.A + s]; }
+        for (u32 s = 0; s < m.A; s++) { H.freq[x * m.A + s] = (u16)(row[2 * s] | (row[2 * s + 1] << 8)); H.cum[x * m.A + s] = (u16)acc; acc += H.freq[x * m.A + s]; }
         if (acc != (1u << CQ_SCALE)) throw bad;
     }
     if ((u64)(rows - in) + 4ull * m.nseg > len) throw bad;
@@ -359,7 +404,7 @@ u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 
     HIP_CHECK(hipMemcpyAsync(d_segBytes, H.segBytes.data(), 4ull * m.nseg, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, c->stream));
     bfq_exscan_u32(c, d_segBytes, d_off, m.nseg, nullptr);
-    KLAUNCH(c, K_MISC, 3.0 * (double)m.n, k_cdc_decode, bfq_grid(m.nseg, 256), 256, d_in + H.hdr, (const u64 *)d_off, (const u32 *)d_segBytes,
+    KLAUNCH(c, K_CODEC, 3.0 * (double)m.n, k_cdc_decode, bfq_grid(m.nseg, 256), 256, d_in + H.hdr, (const u64 *)d_off, (const u32 *)d_segBytes,
             (const u8 *)d_alpha, m, (const u16 *)d_freq, (const u16 *)d_cum, d_out, d_bad);
     u32 bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));

@@ -10,16 +10,22 @@
  * Container (little endian):
  *   char  magic[8] = "BFQRANS1"
  *   u64   raw_len
- *   u32   seg_syms (8192), nseg = ceil(raw_len / seg_syms), A (distinct byte values), k (context order), scale_bits (12)
+ *   u32   seg_syms (8192; halved down to 1024 while raw_len / seg_syms < 65536, so that short streams still fill the GPU),
+ *         nseg = ceil(raw_len / seg_syms), A (distinct byte values), k (context order), scale_bits (12)
  *   u8    alphabet[256]          byte value of symbol 0..A-1, ascending; the rest 0
- *   u8    used[ceil(A^k / 8)]    bit c: context c occurs
+ *   u16   dflt[A]                order-0 row: the model of every context without a row of its own
+ *   u8    used[ceil(A^k / 8)]    bit c: context c has a row (it occurs in the sampled segments)
  *   u16   freq[used contexts][A] in ascending context order, every row sums to 2^scale_bits
  *   u32   seg_bytes[nseg]
  *   u8    payload[]              the segments' rANS streams back to back
  * Context of a symbol = the k symbols before it INSIDE its segment (missing ones count as symbol 0), read as a base-A
- * number, oldest symbol most significant.  k = the largest order with A^(k+1) <= min(2^22, max(4096, raw_len / 16)), at most 8.
- * Model row of a context: f[s] = max(1, floor(count[s] * 2^scale / total)) for count[s] > 0; a surplus over 2^scale is taken
- * from the largest entries (lowest symbol first among equals, never below 1), a deficit goes to the largest entry.
+ * number, oldest symbol most significant.  k = the largest order with A^(k+1) <= min(2^22, max(4096, sampled_len / 16)), at most 8.
+ * The model is counted on a SAMPLE: segments g with g % S == 0, S = clamp(raw_len / 2^24, 1, 64) (k is chosen for the
+ * sampled length raw_len / S) -- a histogram of every symbol
+ * of a 4.5 GB stream into a table of millions of bins is the one step that does not parallelise cheaply.  Every symbol of the
+ * alphabet keeps a non-zero share in every row, so whatever the unsampled segments hold can be coded:
+ * f[s] = max(1, floor(count[s] * 2^scale / total)) for ALL s; a surplus over 2^scale is taken from the largest entries
+ * (lowest symbol first among equals, never below 1), a deficit goes to the largest entry.
  * rANS: state x in [2^23, 2^31), symbols coded last to first, bytes emitted low byte first and stored backwards, so the
  * decoder reads forwards: x = le32, then per symbol slot = x & (2^scale - 1), s = symbol with cum[s] <= slot < cum[s] + f[s],
  * x = f[s] * (x >> scale) + slot - cum[s], while x < 2^23: x = x << 8 | next byte.
@@ -28,7 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define BQC_SEG 8192u
+#define BQC_SEG_MAX 8192u
 #define BQC_SCALE 12u
 #define BQC_L (1u << 23)
 
@@ -48,6 +54,19 @@ static uint32_t choose_k(uint32_t A, uint64_t n)
     return k;
 }
 
+static uint32_t choose_seg(uint64_t n)
+{
+    uint32_t seg = BQC_SEG_MAX;
+    while (seg > 1024 && n / seg < 65536) seg >>= 1;
+    return seg;
+}
+
+static uint32_t sample_step(uint64_t n)
+{
+    uint64_t S = n >> 24;
+    return S < 1 ? 1u : (S > 64 ? 64u : (uint32_t)S);
+}
+
 static void normalise(const uint32_t *cnt, uint32_t A, uint16_t *f)
 {
     const uint32_t M = 1u << BQC_SCALE;
@@ -55,8 +74,8 @@ static void normalise(const uint32_t *cnt, uint32_t A, uint16_t *f)
     for (uint32_t s = 0; s < A; s++) T += cnt[s];
     uint32_t sum = 0;
     for (uint32_t s = 0; s < A; s++) {
-        uint32_t v = 0;
-        if (cnt[s]) { v = (uint32_t)(((uint64_t)cnt[s] * M) / T); if (v == 0) v = 1; }
+        uint32_t v = T ? (uint32_t)(((uint64_t)cnt[s] * M) / T) : 0;
+        if (v == 0) v = 1;
         f[s] = (uint16_t)v; sum += v;
     }
     while (sum > M) {
@@ -82,16 +101,18 @@ int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t c
     uint32_t A = 0;
     for (uint32_t b = 0; b < 256; b++) if (present[b]) { map[b] = A; alphabet[A++] = (uint8_t)b; }
     if (A == 0) A = 1;                                  /* empty input: one dummy symbol */
-    const uint32_t k = choose_k(A, n);
+    const uint32_t S = sample_step(n);
+    const uint32_t k = choose_k(A, n / S);
     uint64_t nctx = 1;
     for (uint32_t j = 0; j < k; j++) nctx *= A;
     const uint64_t top = nctx;                          /* A^k: weight of the symbol that leaves the context */
+    const uint32_t BQC_SEG = choose_seg(n);
     const uint32_t nseg = (uint32_t)((n + BQC_SEG - 1) / BQC_SEG);
     uint32_t *cnt = (uint32_t *)calloc(nctx * A, 4);
     uint16_t *freq = (uint16_t *)calloc(nctx * A, 2), *cum = (uint16_t *)calloc(nctx * A, 2);
-    uint8_t *tmp = (uint8_t *)malloc(2 * BQC_SEG + 16);
+    uint8_t *tmp = (uint8_t *)malloc(2 * BQC_SEG_MAX + 16);
     if (!cnt || !freq || !cum || !tmp) { free(cnt); free(freq); free(cum); free(tmp); return -2; }
-    for (uint32_t g = 0; g < nseg; g++) {
+    for (uint32_t g = 0; g < nseg; g += S) {
         const uint64_t b = (uint64_t)g * BQC_SEG, e = (b + BQC_SEG < n) ? b + BQC_SEG : n;
         uint64_t ctx = 0;
         for (uint64_t i = b; i < e; i++) {
@@ -102,16 +123,22 @@ int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t c
         }
     }
     uint64_t nused = 0;
+    uint32_t cnt0[256] = {0};
+    uint16_t dflt[256] = {0};
+    uint8_t *usedc = (uint8_t *)calloc(nctx, 1);
+    if (!usedc) { free(cnt); free(freq); free(cum); free(tmp); return -2; }
+    for (uint64_t c = 0; c < nctx; c++)
+        for (uint32_t s = 0; s < A; s++) { uint64_t v = (uint64_t)cnt0[s] + cnt[c * A + s]; cnt0[s] = v > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)v; }
+    normalise(cnt0, A, dflt);
     for (uint64_t c = 0; c < nctx; c++) {
         uint64_t T = 0;
         for (uint32_t s = 0; s < A; s++) T += cnt[c * A + s];
-        if (!T) continue;
-        nused++;
-        normalise(cnt + c * A, A, freq + c * A);
+        if (T) { nused++; usedc[c] = 1; normalise(cnt + c * A, A, freq + c * A); }
+        else memcpy(freq + c * A, dflt, 2 * A);
         uint32_t acc = 0;
         for (uint32_t s = 0; s < A; s++) { cum[c * A + s] = (uint16_t)acc; acc += freq[c * A + s]; }
     }
-    const uint64_t hdr = 8 + 8 + 5 * 4 + 256 + (nctx + 7) / 8 + nused * A * 2 + (uint64_t)nseg * 4;
+    const uint64_t hdr = 8 + 8 + 5 * 4 + 256 + 2 * A + (nctx + 7) / 8 + nused * A * 2 + (uint64_t)nseg * 4;
     int64_t ret = -1;
     if (hdr <= cap) {
         uint8_t *p = out;
@@ -119,12 +146,11 @@ int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t c
         put64(p, n); p += 8;
         put32(p, BQC_SEG); put32(p + 4, nseg); put32(p + 8, A); put32(p + 12, k); put32(p + 16, BQC_SCALE); p += 20;
         memcpy(p, alphabet, 256); p += 256;
+        for (uint32_t s = 0; s < A; s++) { p[0] = (uint8_t)dflt[s]; p[1] = (uint8_t)(dflt[s] >> 8); p += 2; }
         memset(p, 0, (nctx + 7) / 8);
         uint8_t *rows = p + (nctx + 7) / 8;
         for (uint64_t c = 0; c < nctx; c++) {
-            uint64_t T = 0;
-            for (uint32_t s = 0; s < A; s++) T += freq[c * A + s];
-            if (!T) continue;
+            if (!usedc[c]) continue;
             p[c >> 3] |= (uint8_t)(1u << (c & 7));
             for (uint32_t s = 0; s < A; s++) { rows[0] = (uint8_t)freq[c * A + s]; rows[1] = (uint8_t)(freq[c * A + s] >> 8); rows += 2; }
         }
@@ -159,7 +185,7 @@ int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t c
         }
         if (ret == 0) ret = (int64_t)used;
     }
-    free(cnt); free(freq); free(cum); free(tmp);
+    free(cnt); free(freq); free(cum); free(tmp); free(usedc);
     return ret;
 }
 
@@ -176,22 +202,26 @@ int64_t orc_codec_decode(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t
     if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
     const uint64_t n = get64(in + 8);
     const uint32_t seg = get32(in + 16), nseg = get32(in + 20), A = get32(in + 24), k = get32(in + 28), scale = get32(in + 32);
-    if (n > cap || seg != BQC_SEG || scale != BQC_SCALE || A == 0 || A > 256 || k > 8 || nseg != (n + seg - 1) / seg) return -1;
+    if (n > cap || seg != choose_seg(n) || scale != BQC_SCALE || A == 0 || A > 256 || k > 8 || nseg != (n + seg - 1) / seg) return -1;
     const uint8_t *alphabet = in + 36;
     uint64_t nctx = 1;
     for (uint32_t j = 0; j < k; j++) { nctx *= A; if (nctx > (1u << 22)) return -1; }
     const uint64_t top = nctx;
-    const uint8_t *used = in + 36 + 256;
-    if (36 + 256 + (nctx + 7) / 8 > len) return -1;
+    if (36 + 256 + 2ull * A + (nctx + 7) / 8 > len) return -1;
+    const uint8_t *dfl = in + 36 + 256;
+    const uint8_t *used = dfl + 2ull * A;
     const uint8_t *rows = used + (nctx + 7) / 8;
     uint16_t *freq = (uint16_t *)calloc(nctx * A, 2), *cum = (uint16_t *)calloc(nctx * A, 2);
     if (!freq || !cum) { free(freq); free(cum); return -1; }
     int64_t ret = (int64_t)n;
     for (uint64_t c = 0; c < nctx && ret >= 0; c++) {
-        if (!((used[c >> 3] >> (c & 7)) & 1)) continue;
-        if ((uint64_t)(rows - in) + 2ull * A > len) { ret = -1; break; }
+        const uint8_t *row = dfl;
+        if ((used[c >> 3] >> (c & 7)) & 1) {
+            if ((uint64_t)(rows - in) + 2ull * A > len) { ret = -1; break; }
+            row = rows; rows += 2ull * A;
+        }
         uint32_t acc = 0;
-        for (uint32_t s = 0; s < A; s++) { freq[c * A + s] = (uint16_t)(rows[0] | (rows[1] << 8)); rows += 2; cum[c * A + s] = (uint16_t)acc; acc += freq[c * A + s]; }
+        for (uint32_t s = 0; s < A; s++) { freq[c * A + s] = (uint16_t)(row[2 * s] | (row[2 * s + 1] << 8)); cum[c * A + s] = (uint16_t)acc; acc += freq[c * A + s]; }
         if (acc != (1u << scale)) ret = -1;
     }
     const uint8_t *segtab = rows;

@@ -31,3 +31,16 @@ def cases():
     # headers
     out["headers"] = np.frombuffer(b"".join(b"@SYN.%d\n" % i for i in range(30000)), np.uint8).copy()
     return out
+
+
+def sampled_case():
+    """150 M symbols: the model is counted on every 8th segment only (S = 8); a symbol ('Z') and a context (a run of 'T')
+    that occur ONLY in unsampled segments must still be coded."""
+    rng = np.random.default_rng(99)
+    n = 150_000_000 + 1234
+    a = rng.choice(np.frombuffer(b"ACGT", np.uint8), n, p=[.4, .3, .2, .1])
+    seg = 2048                                                     # 150 M / 65536 -> segments of 2048
+    a[5 * seg + 100] = ord("Z")
+    a[7 * seg + 1000:7 * seg + 1400] = ord("T")
+    a[40001 * seg + 7:40001 * seg + 9] = ord("Z")
+    return a
