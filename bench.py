@@ -127,7 +127,7 @@ def e2e_host(api, eng, sp, N, L, iters, log):
     return out, pin, tlen, outs
 
 
-def stream_codec(api, eng, outs, lens, N, L, log, with_cpu):
+def stream_codec(api, eng, outs, lens, N, L, log, with_cpu, text=None):
     """the step the reference hands to 7z / bsc (BFQzip.py:253-275) -- the three output streams of the run
     above through the GPU codec (bfq_stream_compress: pinned host buffer in, pinned host buffer out), sizes and wall time;
     with_cpu: bzip2 -9 / xz -2 on the first 32 MB of each stream beside it (the reference's own tools are not in its tree)."""
@@ -171,6 +171,22 @@ def stream_codec(api, eng, outs, lens, N, L, log, with_cpu):
             finally:
                 os.unlink(f.name)
     pout.free(); pback.free()
+    if text is not None:                                         # steps 1-5 in ONE call: FASTQ text in, three containers out
+        zo = {k: api.PinnedBuffer(eng.stream_bound(lens[k]) if lens[k] < (1 << 28) else lens[k]) for k in ("dna", "qs", "hdr")}
+        zb = {k: v.array for k, v in zo.items()}
+        eng.fastq_job([text], streams=True, hdr=True, fastq=False, out=zb, compress=True)
+        t0 = time.perf_counter()
+        z = eng.fastq_job([text], streams=True, hdr=True, fastq=False, out=zb, compress=True)
+        dt = time.perf_counter() - t0
+        same = all(int(len(getattr(z, k))) == res[k]["compressed_bytes"] for k in ("dna", "qs", "hdr"))
+        res["fused_steps_1_to_5"] = {"wall_ms": round(dt * 1e3, 1), "Mbases_per_s": round(N * L / 1e6 / dt, 1),
+                                     "bytes_in": int(len(text)), "bytes_out": int(len(z.dna) + len(z.qs) + len(z.hdr)),
+                                     "containers_equal_separate_run": bool(same),
+                                     "what": "bfq_fastq_run_job with compress_streams: FASTQ text (pinned) -> parse, eBWT, clusters, inversion, "
+                                             "entropy coding, all on the GPU -> three BFQRANS1 containers (pinned); the raw streams never cross the bus"}
+        log(f"fused steps 1-5: {dt * 1e3:.0f} ms")
+        for v in zo.values():
+            v.free()
     res["total"] = {"raw_bytes": int(tot_raw), "compressed_bytes": int(tot_cmp), "ratio": round(tot_raw / max(tot_cmp, 1), 2),
                     "compress_GB_per_s_host_to_host": round(tot_raw / 1e9 / tot_t, 2)}
     res["what"] = ("OUT.fq.dna / OUT.fq.qs / OUT.h of the e2e_host run -> bfq_stream_compress (BFQRANS1: static order-k model + rANS, "
@@ -430,7 +446,7 @@ def main():
                 try:
                     nl = Nw * (L + 1)
                     lens = {"dna": nl, "qs": nl, "hdr": res["e2e_host"]["bytes_out"] - 2 * nl}
-                    res["stream_codec"] = stream_codec(api, eng, outs, lens, Nw, L, log, not args.no_cpu)
+                    res["stream_codec"] = stream_codec(api, eng, outs, lens, Nw, L, log, not args.no_cpu, text)
                 except Exception as e:
                     res["stream_codec"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_e2e:

@@ -64,7 +64,9 @@ class FastqJob(C.Structure):
                 ("fastq_len", C.c_uint64), ("stream_len", C.c_uint64), ("hdr_len", C.c_uint64),
                 ("n_reads", C.c_uint64), ("total_bases", C.c_uint64),
                 ("part_reads", C.c_uint64 * (MAX_PARTS + 1)), ("part_fastq_off", C.c_uint64 * (MAX_PARTS + 1)),
-                ("part_stream_off", C.c_uint64 * (MAX_PARTS + 1)), ("part_hdr_off", C.c_uint64 * (MAX_PARTS + 1))]
+                ("part_stream_off", C.c_uint64 * (MAX_PARTS + 1)), ("part_hdr_off", C.c_uint64 * (MAX_PARTS + 1)),
+                ("compress_streams", C.c_int32), ("reserved0", C.c_int32),
+                ("dna_bytes", C.c_uint64), ("qs_bytes", C.c_uint64), ("hdr_bytes", C.c_uint64)]
 
 
 def build(clean=False):

@@ -209,11 +209,12 @@ class Engine:
         return (dna[:sl.value].tobytes(), qs[:sl.value].tobytes(),
                 hdr[:hl.value].tobytes() if want_headers else None, st.as_dict())
 
-    def fastq_job(self, parts, keep_headers=False, fastq=True, streams=False, hdr=False, out=None):
+    def fastq_job(self, parts, keep_headers=False, fastq=True, streams=False, hdr=False, out=None, compress=False):
         """One block of BFQzip_parallel.py in one call (bfq_fastq_run_job): `parts` = 1..4 byte ranges (bytes,
         uint8 arrays, memmap slices) processed as one collection; outputs as asked: the FASTQ text, the --m2
         streams (dna, qs), the --m3 header stream.  `out` may give reusable output arrays (e.g. PinnedBuffer.array)
-        under the keys 'fastq', 'dna', 'qs', 'hdr'."""
+        under the keys 'fastq', 'dna', 'qs', 'hdr'.  compress=True: the streams come back as BFQRANS1 containers
+        (steps 1-5 of the reference in one call; stream_decompress gives the raw stream)."""
         arrs = [_u8(p) for p in parts]
         np_ = len(arrs)
         tp = (_lib.TextPart * np_)()
@@ -230,6 +231,7 @@ class Engine:
             return b if b is not None else np.empty(size, np.uint8)
         J = _lib.FastqJob()
         J.parts = tp; J.nparts = np_; J.keep_headers = 1 if keep_headers else 0
+        J.compress_streams = 1 if compress else 0
         bf = buf("fastq", fastq, inlen + 5 * np_ + 16)
         bd, bq = buf("dna", streams, inlen + 16), buf("qs", streams, inlen + 16)
         bh = buf("hdr", hdr, inlen + 16)
@@ -243,9 +245,9 @@ class Engine:
         self._ck(self.L.bfq_fastq_run_job(self.h, C.byref(J), C.byref(st)))
         r = JobResult()
         r.fastq = bf[:J.fastq_len] if bf is not None else None
-        r.dna = bd[:J.stream_len] if bd is not None else None
-        r.qs = bq[:J.stream_len] if bq is not None else None
-        r.hdr = bh[:J.hdr_len] if bh is not None else None
+        r.dna = bd[:J.dna_bytes] if bd is not None else None
+        r.qs = bq[:J.qs_bytes] if bq is not None else None
+        r.hdr = bh[:J.hdr_bytes] if bh is not None else None
         r.n_reads, r.total_bases = int(J.n_reads), int(J.total_bases)
         r.part_reads = [int(J.part_reads[i]) for i in range(np_ + 1)]
         r.part_fastq_off = [int(J.part_fastq_off[i]) for i in range(np_ + 1)]
@@ -302,9 +304,9 @@ class Engine:
         self._ck(self.L.bfq_glob_finish(self.h, dna.data_ptr() if sl else None, qs.data_ptr() if sl else None, C.byref(J)))
         r = JobResult()
         r.fastq = bf[:J.fastq_len] if bf is not None else None
-        r.dna = bd[:J.stream_len] if bd is not None else None
-        r.qs = bq[:J.stream_len] if bq is not None else None
-        r.hdr = bh[:J.hdr_len] if bh is not None else None
+        r.dna = bd[:J.dna_bytes] if bd is not None else None
+        r.qs = bq[:J.qs_bytes] if bq is not None else None
+        r.hdr = bh[:J.hdr_bytes] if bh is not None else None
         r.n_reads, r.total_bases = int(J.n_reads), int(J.total_bases)
         r.part_reads = [int(J.part_reads[i]) for i in range(nparts + 1)]
         r.part_fastq_off = [int(J.part_fastq_off[i]) for i in range(nparts + 1)]

@@ -764,6 +764,8 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         if (!J || J->nparts < 1 || J->nparts > BFQ_MAX_PARTS || !J->parts) throw BfqError{BFQ_E_ARG, "bfq_fastq_job: 1..BFQ_MAX_PARTS parts"};
         const int np = J->nparts;
         J->fastq_len = J->stream_len = J->hdr_len = J->n_reads = J->total_bases = 0;
+        J->dna_bytes = J->qs_bytes = J->hdr_bytes = 0;
+        const bool cz = J->compress_streams != 0;
         std::vector<u64> ps;
         TextSrc src[BFQ_MAX_PARTS];
         for (int p = 0; p < np; p++) src[p] = TextSrc{HostRef::mem(J->parts[p].data), J->parts[p].len};
@@ -790,19 +792,37 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
             u64 hl = 0;
             bfq_fastq_hdr_stream(c, fq.N, d_fq, &fq, &d_hdr, &hl, &hOff);
             J->hdr_len = hl;
-            if (hl > J->cap_hdr) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
-            bfq_download(c, J->out_hdr, d_hdr, hl);
+            if (cz) {                                          // step 5 on the device: only the container crosses the bus
+                const size_t mz = c->mark();
+                const u64 bound = bfq_codec_bound(hl) < J->cap_hdr ? bfq_codec_bound(hl) : J->cap_hdr;
+                u8 *d_z = c->alloc<u8>(bound + 16);
+                J->hdr_bytes = bfq_codec_compress_device(c, d_hdr, hl, d_z, bound);
+                bfq_download(c, J->out_hdr, d_z, J->hdr_bytes);
+                c->release(mz);
+            } else {
+                if (hl > J->cap_hdr) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
+                bfq_download(c, J->out_hdr, d_hdr, hl);
+                J->hdr_bytes = hl;
+            }
             bfq_pick_u64(c, hOff, d_pidx, np + 1, 0, d_pick + 3 * (np + 1));
             pickH = true;
         }
         if (wantStreams) { bfq_pick_u64(c, fq.roff, d_pidx, np + 1, 1, d_pick + 2 * (np + 1)); pickS = true; }   // roff[i] + i
         size_t m = c->mark();
         bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
-        StreamOut so{J->out_dna, J->out_qs};
+        StreamOut so{cz ? nullptr : J->out_dna, cz ? nullptr : J->out_qs};
         steps234_device(c, fq.roff, ob, oq, nullptr, lines ? &so : nullptr);
-        if (lines) J->stream_len = sl;
+        if (lines) { J->stream_len = sl; if (!cz) { J->dna_bytes = J->out_dna ? sl : 0; J->qs_bytes = J->out_qs ? sl : 0; } }
         c->release(m);                                         // the formatted text may reuse the pipeline's space:
         c->d_bwt = c->d_qual = nullptr; c->d_lcp = nullptr; c->d_gcnt = nullptr;   // the eBWT is gone (bfq_fetch_ebwt refuses)
+        if (lines && cz) {                                     // step 5 on the device, in the space the pipeline has left
+            const size_t mz = c->mark();
+            const u64 bound = bfq_codec_bound(sl) < J->cap_stream ? bfq_codec_bound(sl) : J->cap_stream;
+            u8 *d_z = c->alloc<u8>(bound + 16);
+            if (J->out_dna) { J->dna_bytes = bfq_codec_compress_device(c, ob, sl, d_z, bound); bfq_download(c, J->out_dna, d_z, J->dna_bytes); }
+            if (J->out_qs) { J->qs_bytes = bfq_codec_compress_device(c, oq, sl, d_z, bound); bfq_download(c, J->out_qs, d_z, J->qs_bytes); }
+            c->release(mz);
+        }
         if (J->out_fastq) {
             u8 *d_out = nullptr;
             u64 *recOff = nullptr;
@@ -977,6 +997,7 @@ extern "C" int bfq_stream_compress(bfq_ctx *c, const uint8_t *h_in, uint64_t len
         if (len) bfq_upload(c, d_in, h_in, len);
         const u64 got = bfq_codec_compress_device(c, d_in, len, d_out, bound);
         bfq_download(c, h_out, d_out, got);
+        c->sync();                                             // pinned destinations are written by asynchronous DMA
         c->profCollect();
         *out_len = got;
     });
@@ -992,6 +1013,7 @@ extern "C" int bfq_stream_decompress(bfq_ctx *c, const uint8_t *h_in, uint64_t l
         bfq_upload(c, d_in, h_in, len);
         const u64 got = bfq_codec_decompress_device(c, h_in, d_in, len, d_out, raw);
         if (got) bfq_download(c, h_out, d_out, got);
+        c->sync();
         c->profCollect();
         *out_len = got;
     });
@@ -1006,6 +1028,7 @@ extern "C" int bfq_stream_compress_device(bfq_ctx *c, const uint8_t *d_in, uint6
     return guarded(c, [&] {
         c->wsTop = 0;
         *out_len = bfq_codec_compress_device(c, d_in, len, d_out, cap);
+        c->sync();
         c->profCollect();
     });
 }

@@ -202,6 +202,7 @@ extern "C" int bfq_glob_finish(bfq_ctx *c, uint8_t *d_dna, uint8_t *d_qs, bfq_fa
         const u64 sl = fq.total + fq.N;
         J->n_reads = fq.N; J->total_bases = fq.total;
         J->fastq_len = J->stream_len = J->hdr_len = 0;
+        J->dna_bytes = J->qs_bytes = J->hdr_bytes = 0;               // (compress_streams is not offered here: raw streams)
         if (c->P.B && sl) KLAUNCH(c, K_MISC, 2.0 * (double)sl, k_bin_lines, bfq_grid(sl, 256), 256, d_qs, sl);
         const int np = c->residentParts;
         u64 *d_pidx = c->alloc<u64>(np + 1), *d_pick = c->alloc<u64>(4 * (np + 1));
@@ -215,7 +216,7 @@ extern "C" int bfq_glob_finish(bfq_ctx *c, uint8_t *d_dna, uint8_t *d_qs, bfq_fa
             u64 *hOff = nullptr;
             u64 hl = 0;
             bfq_fastq_hdr_stream(c, fq.N, c->d_text, &fq, &d_hdr, &hl, &hOff);
-            J->hdr_len = hl;
+            J->hdr_len = J->hdr_bytes = hl;
             if (hl > J->cap_hdr) throw BfqError{BFQ_E_ARG, "stream buffer too small"};
             bfq_download(c, J->out_hdr, d_hdr, hl);
             bfq_pick_u64(c, hOff, d_pidx, np + 1, 0, d_pick + 3 * (np + 1));
@@ -224,8 +225,8 @@ extern "C" int bfq_glob_finish(bfq_ctx *c, uint8_t *d_dna, uint8_t *d_qs, bfq_fa
         if (J->out_dna || J->out_qs) {
             if (sl > J->cap_stream) throw BfqError{BFQ_E_ARG, "stream buffer too small"};
             J->stream_len = sl;
-            if (J->out_dna) bfq_download(c, J->out_dna, d_dna, sl);
-            if (J->out_qs) bfq_download(c, J->out_qs, d_qs, sl);
+            if (J->out_dna) { bfq_download(c, J->out_dna, d_dna, sl); J->dna_bytes = sl; }
+            if (J->out_qs) { bfq_download(c, J->out_qs, d_qs, sl); J->qs_bytes = sl; }
         }
         if (J->out_fastq) {
             u8 *d_out = nullptr;

@@ -162,6 +162,11 @@ typedef struct bfq_fastq_job {
     uint64_t fastq_len, stream_len, hdr_len, n_reads, total_bases;
     uint64_t part_reads[BFQ_MAX_PARTS + 1], part_fastq_off[BFQ_MAX_PARTS + 1],
              part_stream_off[BFQ_MAX_PARTS + 1], part_hdr_off[BFQ_MAX_PARTS + 1];
+    /* steps 1-5 in one call: the streams leave as BFQRANS1 containers (bfq_stream_compress, below) instead of raw bytes --
+     * what `BFQzip.py --m2/--m3` without -0 produces through 7z / bsc (BFQzip.py:253-275).  The raw streams never cross
+     * the bus.  stream_len / hdr_len stay the RAW lengths; *_bytes = what was written to out_dna / out_qs / out_hdr. */
+    int32_t  compress_streams; int32_t reserved0;
+    uint64_t dna_bytes, qs_bytes, hdr_bytes;
 } bfq_fastq_job;
 int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *job, bfq_stats *st);
 

@@ -46,6 +46,26 @@ def test_pipeline_streams(engine):
     assert sizes["hdr"][1] < 0.35 * sizes["hdr"][0]
 
 
+def test_job_with_compressed_streams(engine):
+    """Steps 1-5 in one call (bfq_fastq_job.compress_streams): the containers hold the streams of the plain job."""
+    sp = api.synth_spec(50000, 80, Lmax=120, seed=11)
+    text = np.empty(50000 * 300, np.uint8)
+    n = engine.synth_fastq(sp, text)
+    engine.set_params(m=5)
+    plain = engine.fastq_job([text[:n]], keep_headers=True, fastq=True, streams=True, hdr=True)
+    z = engine.fastq_job([text[:n]], keep_headers=True, fastq=True, streams=True, hdr=True, compress=True)
+    assert z.stats == plain.stats and np.array_equal(z.fastq, plain.fastq)
+    for a, b in ((z.dna, plain.dna), (z.qs, plain.qs), (z.hdr, plain.hdr)):
+        a = np.asarray(a)
+        assert bytes(a[:8]) == b"BFQRANS1" and len(a) < len(b)
+        assert np.array_equal(np.asarray(engine.stream_decompress(a)), np.asarray(b))
+        assert np.array_equal(orc.codec_encode(np.asarray(b)), a)
+    # two parts (paired blocks): the containers cover the whole collection
+    half = int(api.text_nth_newline(text[:n], 4 * 25000 - 1)) + 1
+    z2 = engine.fastq_job([text[:half], text[half:n]], fastq=False, streams=True, compress=True)
+    assert np.array_equal(np.asarray(engine.stream_decompress(np.asarray(z2.qs))), np.asarray(plain.qs))
+
+
 def test_large_stream_round_trip(engine):
     """More segments than one launch has lanes, a model table near its largest size (6 symbols, order 6)."""
     rng = np.random.default_rng(5)
