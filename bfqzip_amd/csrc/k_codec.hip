@@ -92,9 +92,10 @@ __global__ __launch_bounds__(256) void k_cdc_count(const u8 *__restrict__ in, co
         if (ccnt[j]) atomicAdd(&cnt[ctag[j]], ccnt[j]);
 }
 
+// fc[context * A + symbol] = frequency | cumulative frequency << 16: one look-up per symbol.  Emitted bytes are collected
+// eight at a time (the stream grows towards lower addresses: the oldest byte of a group is its most significant one).
 __global__ __launch_bounds__(256) void k_cdc_encode(const u8 *__restrict__ in, const u8 *__restrict__ map, CdcModel m,
-                                                    const u16 *__restrict__ freq, const u16 *__restrict__ cum,
-                                                    u8 *__restrict__ scratch, u32 *__restrict__ segBytes)
+                                                    const u32 *__restrict__ fc, u8 *__restrict__ scratch, u32 *__restrict__ segBytes)
 {
     __shared__ u8 smap[256];
     smap[threadIdx.x] = map[threadIdx.x];
@@ -109,22 +110,68 @@ __global__ __launch_bounds__(256) void k_cdc_encode(const u8 *__restrict__ in, c
         }
         u8 *const slotEnd = scratch + (g + 1) * (u64)CQ_SLOT(m.seg);
         u8 *q = slotEnd;
+        u64 acc = 0;
+        u32 nacc = 0;
         u32 x = CQ_L;
         u32 s = smap[in[e - 1]];
-        for (u64 i = e; i-- > b;) {
-            const u32 f = freq[(u64)ctx * m.A + s], c0 = cum[(u64)ctx * m.A + s];
-            const u32 xmax = ((CQ_L >> CQ_SCALE) << 8) * f;
-            while (x >= xmax) { *--q = (u8)x; x >>= 8; }
-            x = ((x / f) << CQ_SCALE) + (x % f) + c0;
-            if (i > b) {                                           // the symbol in front, and the context in front of it
-                const u32 prev = smap[in[i - 1]];
-                if (m.k) {
-                    const u32 incoming = (i - 1 >= b + m.k) ? smap[in[i - 1 - m.k]] : 0u;
-                    ctx = (ctx + incoming * m.top - prev) / m.A;
+#define CDC_CODE_ONE()                                                                                         \
+        {                                                                                                      \
+            const u32 t = fc[(u64)ctx * m.A + s];                                                              \
+            const u32 f = t & 0xFFFFu, c0 = t >> 16;                                                           \
+            const u32 xmax = ((CQ_L >> CQ_SCALE) << 8) * f;                                                    \
+            while (x >= xmax) {                                                                                \
+                acc = (acc << 8) | (x & 0xFFu); x >>= 8;                                                       \
+                if (++nacc == 8) { q -= 8; *(u64 *)q = acc; nacc = 0; }                                        \
+            }                                                                                                  \
+            const u32 d = x / f;                                                                               \
+            x = (d << CQ_SCALE) + (x - d * f) + c0;                                                            \
+        }
+        if (((e - b) & 15u) == 0 && (((u64)in + b) & 15u) == 0) {
+            // whole 16-symbol groups: the input arrives as one 16-byte load per group (one request instead of 32 byte
+            // loads -- with a segment per lane every byte load is its own L2 request); w[0..1] = the group in front
+            // (the symbols that leave the context live there), w[2..3] = this group
+            u64 w[4];
+            {
+                const ulonglong2 v = *(const ulonglong2 *)(in + e - 16);
+                w[2] = v.x; w[3] = v.y;
+            }
+            for (u64 cb = e - 16;; cb -= 16) {
+                if (cb > b) { const ulonglong2 v = *(const ulonglong2 *)(in + cb - 16); w[0] = v.x; w[1] = v.y; }
+                else { w[0] = 0; w[1] = 0; }
+#pragma unroll
+                for (int j = 15; j >= 0; j--) {
+                    CDC_CODE_ONE();
+                    const u64 i = cb + (u64)j;
+                    if (i > b) {
+                        const u32 tp = 16u + (u32)j - 1u;                                  // position of symbol i-1 in the window
+                        const u32 prev = smap[(u8)(w[tp >> 3] >> (8u * (tp & 7u)))];
+                        if (m.k) {
+                            const u32 ti = tp - m.k;                                       // ... and of symbol i-1-k (wave-uniform)
+                            const u64 wi = (ti >> 3) == 0 ? w[0] : (ti >> 3) == 1 ? w[1] : (ti >> 3) == 2 ? w[2] : w[3];
+                            const u32 incoming = (i - 1 >= b + m.k) ? smap[(u8)(wi >> (8u * (ti & 7u)))] : 0u;
+                            ctx = (ctx + incoming * m.top - prev) / m.A;
+                        }
+                        s = prev;
+                    }
                 }
-                s = prev;
+                if (cb == b) break;
+                w[2] = w[0]; w[3] = w[1];
+            }
+        } else {
+            for (u64 i = e; i-- > b;) {
+                CDC_CODE_ONE();
+                if (i > b) {                                       // the symbol in front, and the context in front of it
+                    const u32 prev = smap[in[i - 1]];
+                    if (m.k) {
+                        const u32 incoming = (i - 1 >= b + m.k) ? smap[in[i - 1 - m.k]] : 0u;
+                        ctx = (ctx + incoming * m.top - prev) / m.A;
+                    }
+                    s = prev;
+                }
             }
         }
+#undef CDC_CODE_ONE
+        while (nacc) { nacc--; *--q = (u8)(acc >> (8u * nacc)); }   // the oldest of the pending bytes first
         q -= 4;
         q[0] = (u8)x; q[1] = (u8)(x >> 8); q[2] = (u8)(x >> 16); q[3] = (u8)(x >> 24);
         segBytes[g] = (u32)(slotEnd - q);
@@ -145,6 +192,7 @@ __global__ __launch_bounds__(256) void k_cdc_pack(const u8 *__restrict__ scratch
     }
 }
 
+// The generic decoder: any alphabet; the symbol of a slot by binary search in the context's cumulative row.
 __global__ __launch_bounds__(256) void k_cdc_decode(const u8 *__restrict__ pay, const u64 *__restrict__ off,
                                                     const u32 *__restrict__ segBytes, const u8 *__restrict__ alphabet, CdcModel m,
                                                     const u16 *__restrict__ freq, const u16 *__restrict__ cum,
@@ -164,22 +212,61 @@ __global__ __launch_bounds__(256) void k_cdc_decode(const u8 *__restrict__ pay, 
         for (u64 i = b; i < e && ok; i++) {
             const u32 slot = x & ((1u << CQ_SCALE) - 1u);
             const u16 *fr = freq + (u64)ctx * m.A, *cu = cum + (u64)ctx * m.A;
-            u32 s = 0;
-            if (m.A <= 16) {
-                while (s < m.A && !(fr[s] && slot < (u32)cu[s] + fr[s])) s++;
-            } else {                                               // last symbol whose cumulative count is <= slot, then back over absent ones
-                u32 lo = 0, hi = m.A;
-                while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((u32)cu[mid] <= slot) lo = mid; else hi = mid; }
-                s = lo;
-                while (s > 0 && fr[s] == 0) s--;
-                if (!(fr[s] && slot >= (u32)cu[s] && slot < (u32)cu[s] + fr[s])) s = m.A;
-            }
-            if (s >= m.A) { ok = false; break; }
+            u32 lo = 0, hi = m.A;                                  // every row gives every symbol a share: cum is strictly increasing
+            while (hi - lo > 1) { const u32 mid = (lo + hi) >> 1; if ((u32)cu[mid] <= slot) lo = mid; else hi = mid; }
+            const u32 s = lo;
             x = fr[s] * (x >> CQ_SCALE) + slot - cu[s];
             while (x < CQ_L) { if (q >= qe) { ok = false; break; } x = (x << 8) | *q++; }
             out[i] = salpha[s];
             ctx = cdc_next_ctx(ctx, s, win, m);
         }
+        if (!ok) atomicAdd(bad, 1u);
+    }
+}
+
+// Alphabets of up to 8 symbols (the DNA stream, binned qualities): a context's whole row is ONE 16-byte load (rows padded to
+// 8 entries), the stream is read 8 bytes at a time and the output leaves 8 symbols at a time -- with a segment per lane
+// every narrow access is its own L2 request, and those requests, not the arithmetic, were the decoder's time.
+__global__ __launch_bounds__(256) void k_cdc_decode8(const u8 *__restrict__ pay, const u64 *__restrict__ off,
+                                                     const u32 *__restrict__ segBytes, const u8 *__restrict__ alphabet, CdcModel m,
+                                                     const u16 *__restrict__ freq8, u8 *__restrict__ out, u32 *__restrict__ bad)
+{
+    __shared__ u8 salpha[256];
+    salpha[threadIdx.x] = alphabet[threadIdx.x];
+    __syncthreads();
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < m.nseg; g += (u64)gridDim.x * blockDim.x) {
+        const u8 *q = pay + off[g];
+        const u32 nbytes = segBytes[g];
+        u32 x = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+        u32 used = 4;                                              // bytes of the stream consumed so far
+        u64 ib = 0;                                                // bytes not yet consumed, the next one in the low byte
+        u32 ni = 0;
+        const u64 b = g * m.seg, e = (b + m.seg < m.n) ? b + m.seg : m.n;
+        u32 ctx = 0;
+        u64 win = 0, ob = 0;
+        bool ok = true;
+        for (u64 i = b; i < e; i++) {
+            const u32 slot = x & ((1u << CQ_SCALE) - 1u);
+            const uint4 row = *(const uint4 *)(freq8 + (u64)ctx * 8);
+            const u32 fw[4] = {row.x, row.y, row.z, row.w};
+            u32 s = 0, c0 = 0, f = fw[0] & 0xFFFFu;
+#pragma unroll
+            for (int t = 1; t < 8; t++) {                          // first symbol whose share reaches past the slot
+                const u32 ft = (t & 1) ? fw[t >> 1] >> 16 : fw[t >> 1] & 0xFFFFu;
+                const bool past = slot >= c0 + f;
+                c0 = past ? c0 + f : c0; s = past ? (u32)t : s; f = past ? ft : f;
+            }
+            x = f * (x >> CQ_SCALE) + slot - c0;
+            while (x < CQ_L) {
+                if (ni == 0) { ib = (used < nbytes) ? *(const u64 *)(q + used) : 0ull; ni = 8; }   // (the buffer is padded by 16 bytes; a damaged stream reads zeros, not memory)
+                x = (x << 8) | (u32)(ib & 0xFFu); ib >>= 8; ni--; used++;
+            }
+            ob |= (u64)salpha[s] << (8u * (u32)((i - b) & 7u));
+            if (((i - b) & 7u) == 7u) { *(u64 *)(out + i - 7) = ob; ob = 0; }
+            ctx = cdc_next_ctx(ctx, s, win, m);
+        }
+        for (u64 i = e - ((e - b) & 7u); i < e; i++) out[i] = (u8)(ob >> (8u * (u32)((i - b) & 7u)));   // a last segment that is no multiple of 8
+        if (used > nbytes) ok = false;
         if (!ok) atomicAdd(bad, 1u);
     }
 }
@@ -298,17 +385,18 @@ u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 
     }
     const u64 hdr = 36 + 256 + 2ull * A + used.size() + nused * A * 2 + 4ull * m.nseg;
     if (hdr > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
-    u16 *d_freq = c->alloc<u16>(E), *d_cum = c->alloc<u16>(E);
-    HIP_CHECK(hipMemcpyAsync(d_freq, freq.data(), 2 * E, hipMemcpyHostToDevice, c->stream));
-    HIP_CHECK(hipMemcpyAsync(d_cum, cum.data(), 2 * E, hipMemcpyHostToDevice, c->stream));
+    std::vector<u32> fcv(E);
+    for (u64 x = 0; x < E; x++) fcv[x] = (u32)freq[x] | ((u32)cum[x] << 16);
+    u32 *d_fc = c->alloc<u32>(E);
+    HIP_CHECK(hipMemcpyAsync(d_fc, fcv.data(), 4 * E, hipMemcpyHostToDevice, c->stream));
     u32 *d_segBytes = c->alloc<u32>(m.nseg + 1);
     u64 *d_off = c->alloc<u64>(m.nseg + 1), *d_total = c->alloc<u64>(1);
     u8 *scratch = c->alloc<u8>((u64)m.nseg * CQ_SLOT(m.seg) + 16);
     u64 total = 0;
     std::vector<u32> segBytes(m.nseg);
     if (m.nseg) {
-        KLAUNCH(c, K_CODEC, 3.0 * (double)n, k_cdc_encode, bfq_grid(m.nseg, 256), 256, d_in, (const u8 *)d_map, m, (const u16 *)d_freq,
-                (const u16 *)d_cum, scratch, d_segBytes);
+        KLAUNCH(c, K_CODEC, 3.0 * (double)n, k_cdc_encode, bfq_grid(m.nseg, 256), 256, d_in, (const u8 *)d_map, m, (const u32 *)d_fc,
+                scratch, d_segBytes);
         bfq_exscan_u32(c, d_segBytes, d_off, m.nseg, d_total);
         HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipMemcpyAsync(segBytes.data(), d_segBytes, 4ull * m.nseg, hipMemcpyDeviceToHost, c->stream));
@@ -404,8 +492,18 @@ u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 
     HIP_CHECK(hipMemcpyAsync(d_segBytes, H.segBytes.data(), 4ull * m.nseg, hipMemcpyHostToDevice, c->stream));
     HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, c->stream));
     bfq_exscan_u32(c, d_segBytes, d_off, m.nseg, nullptr);
-    KLAUNCH(c, K_CODEC, 3.0 * (double)m.n, k_cdc_decode, bfq_grid(m.nseg, 256), 256, d_in + H.hdr, (const u64 *)d_off, (const u32 *)d_segBytes,
-            (const u8 *)d_alpha, m, (const u16 *)d_freq, (const u16 *)d_cum, d_out, d_bad);
+    if (m.A <= 8) {                                                // rows padded to 8 entries: one aligned 16-byte load per symbol
+        std::vector<u16> f8((u64)m.top * 8, 0);
+        for (u64 x = 0; x < m.top; x++)
+            for (u32 t = 0; t < m.A; t++) f8[x * 8 + t] = H.freq[x * m.A + t];
+        u16 *d_f8 = c->alloc<u16>((u64)m.top * 8);
+        HIP_CHECK(hipMemcpyAsync(d_f8, f8.data(), 16ull * m.top, hipMemcpyHostToDevice, c->stream));
+        KLAUNCH(c, K_CODEC, 3.0 * (double)m.n, k_cdc_decode8, bfq_grid(m.nseg, 256), 256, d_in + H.hdr, (const u64 *)d_off, (const u32 *)d_segBytes,
+                (const u8 *)d_alpha, m, (const u16 *)d_f8, d_out, d_bad);
+        c->sync();                                                 // f8 is a host temporary
+    } else
+        KLAUNCH(c, K_CODEC, 3.0 * (double)m.n, k_cdc_decode, bfq_grid(m.nseg, 256), 256, d_in + H.hdr, (const u64 *)d_off, (const u32 *)d_segBytes,
+                (const u8 *)d_alpha, m, (const u16 *)d_freq, (const u16 *)d_cum, d_out, d_bad);
     u32 bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
     c->sync();
