@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                 const bool act = lane < rows;
                 // working form of the payload: word index and bit offset of text position p + 16 instead of p,
                 // so that the word of every later round (+21 symbols = +1 word) needs no division
-                u64 v = act ? wo_from_pay(rec_pay(rec, myRow)) : 0ull;
+                // the key bits of a segment's rows are all the same: kept from this load, the write-back needs no second one
+                const u64 x0 = act ? rec.w12[myRow] : 0ull;
+                const u32 keyBits = (u32)x0 & 0xFFFF0000u;
+                u64 v = act ? wo_from_pay(bfq_rec_pay((u32)x0, (u32)(x0 >> 32))) : 0ull;
                 u32 mylcp = LCP_PENDING;                                            // positional: LCP(row-1,row)
                 u64 unres = __ballot(act);
                 u64 curHeads = ~0ull;                                               // head lanes of the current sub-segments
@@ -236,7 +239,8 @@ __global__ __launch_bounds__(256) void k_refine_chunk(SortRec rec, u16 *__restri
                     round += 2;
                 }
                 if (act) {
-                    rec_set_pay(rec, myRow, wo_to_pay(v));
+                    const u64 pay = wo_to_pay(v);
+                    rec.w12[myRow] = ((u64)(u32)pay << 32) | keyBits | (u32)(pay >> 32);
                     if ((int)lane != seglo) lcp[myRow] = (u16)mylcp;
                 }
                 done += ntake;
