@@ -81,6 +81,24 @@ def test_large_stream_round_trip(engine):
     assert len(blob) < 0.275 * len(raw)                       # 2 bits per base + N, newlines, 8 bytes per 1024-symbol segment
 
 
+def test_random_streams(engine):
+    """Random alphabets (1..256 symbols), lengths around the segment and group boundaries, skews and run structures:
+    the GPU container equals the CPU statement and decodes back."""
+    rng = np.random.default_rng(31337)
+    for it in range(150):
+        A = int(rng.choice([1, 2, 3, 5, 6, 8, 9, 16, 17, 42, 64, 200, 256]))
+        n = int(rng.choice([0, 1, 7, 15, 16, 17, 1023, 1024, 1025, 4097, 20000, 70001, 250000]))
+        syms = rng.permutation(256)[:A].astype(np.uint8)
+        p = rng.dirichlet(np.full(A, float(rng.choice([0.05, 0.3, 1.0, 5.0]))))
+        data = rng.choice(syms, n, p=p) if n else np.zeros(0, np.uint8)
+        if n and rng.random() < 0.4:                               # runs: repeat every symbol a few times
+            data = np.repeat(data, rng.integers(1, 6, n))[:n]
+        blob = np.asarray(engine.stream_compress(data))
+        want = orc.codec_encode(data)
+        assert len(blob) == len(want) and (blob == want).all(), (it, A, n)
+        assert (np.asarray(engine.stream_decompress(blob)) == data).all(), (it, A, n)
+
+
 def test_sampled_model(engine):
     """> 8192 segments: the model comes from every second segment; the container still equals the CPU statement."""
     data = sampled_case()
