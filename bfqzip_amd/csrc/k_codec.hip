@@ -78,13 +78,25 @@ __global__ __launch_bounds__(256) void k_cdc_count(const u8 *__restrict__ in, co
         const u64 b = g * m.seg, e = (b + m.seg < m.n) ? b + m.seg : m.n;
         u32 ctx = 0, lastKey = 0xFFFFFFFFu, run = 0;
         u64 win = 0;
-        for (u64 i = b; i < e; i++) {
-            const u32 s = smap[in[i]];
-            const u32 key = ctx * m.A + s;
-            if (key == lastKey) run++;
-            else { if (run) cdc_add(ctag, ccnt, cnt, lastKey, run); lastKey = key; run = 1; }
-            ctx = cdc_next_ctx(ctx, s, win, m);
+#define CDC_COUNT_ONE(byte)                                                                                  \
+        {                                                                                                      \
+            const u32 s = smap[(u8)(byte)];                                                                    \
+            const u32 key = ctx * m.A + s;                                                                     \
+            if (key == lastKey) run++;                                                                         \
+            else { if (run) cdc_add(ctag, ccnt, cnt, lastKey, run); lastKey = key; run = 1; }                  \
+            ctx = cdc_next_ctx(ctx, s, win, m);                                                                \
         }
+        u64 i = b;
+        if ((((u64)in + b) & 15u) == 0)
+            for (; i + 16 <= e; i += 16) {                         // 16 symbols per memory request
+                const ulonglong2 v = *(const ulonglong2 *)(in + i);
+#pragma unroll
+                for (int j = 0; j < 8; j++) CDC_COUNT_ONE(v.x >> (8 * j));
+#pragma unroll
+                for (int j = 0; j < 8; j++) CDC_COUNT_ONE(v.y >> (8 * j));
+            }
+        for (; i < e; i++) CDC_COUNT_ONE(in[i]);
+#undef CDC_COUNT_ONE
         if (run) cdc_add(ctag, ccnt, cnt, lastKey, run);
     }
     __syncthreads();

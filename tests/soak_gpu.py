@@ -9,7 +9,7 @@ Round 2 adds per case: step 1 in one piece or pile by pile (drawn at random; BFQ
 every pile again), bfq_int mode = LCP deduced from the BWT alone (k_bfs.hip), on small cases also with the ties of
 identical suffixes shuffled, the FASTQ job (text in, FASTQ text + streams out) against the oracle's reads, and the global mode
 (parallel.run_global on one rank: two-symbol piles, position-mode clusters) against the same.
-Round 2 totals: 21 793 cases / 5.8 G rows in ten runs (the last five with the 40-bit sort key), all bit-exact."""
+Round 2 totals: 25 623 cases / 6.8 G rows in twelve runs (the last seven with the 40-bit sort key), all bit-exact."""
 import sys, time, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
