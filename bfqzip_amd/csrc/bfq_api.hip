@@ -1011,7 +1011,12 @@ extern "C" int bfq_stream_decompress(bfq_ctx *c, const uint8_t *h_in, uint64_t l
         c->reserve(bfq_codec_workspace(raw) + len);
         u8 *d_in = c->alloc<u8>(len + 16), *d_out = c->alloc<u8>(raw + 16);
         bfq_upload(c, d_in, h_in, len);
-        const u64 got = bfq_codec_decompress_device(c, h_in, d_in, len, d_out, raw);
+        u64 got = 0;
+        for (u64 pos = 0; pos < len;) {                            // one container per block of a sharded run, back to back
+            const u64 ml = bfq_codec_member_len(h_in + pos, len - pos);
+            got += bfq_codec_decompress_device(c, h_in + pos, d_in + pos, ml, d_out + got, raw - got);
+            pos += ml;
+        }
         if (got) bfq_download(c, h_out, d_out, got);
         c->sync();
         c->profCollect();

@@ -167,7 +167,8 @@ void bfq_exscan_u64(bfq_ctx *c, const u64 *in, u64 *out, u64 n, u64 *d_total);
 // stream codec (k_codec.hip)
 u64 bfq_codec_bound(u64 n);
 u64 bfq_codec_workspace(u64 n);
-u64 bfq_codec_raw_len(const u8 *h_in, u64 len);
+u64 bfq_codec_raw_len(const u8 *h_in, u64 len);                    // all members of a file
+u64 bfq_codec_member_len(const u8 *h_in, u64 len);                 // bytes of the first member
 u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap);
 u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap);
 

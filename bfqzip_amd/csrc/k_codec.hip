@@ -477,10 +477,25 @@ static void cdc_parse(const u8 *in, u64 len, CdcHeader &H)
     if (H.hdr + total > len) throw bad;
 }
 
+// A file may hold several containers back to back (one per block of a sharded run: bfqzip_amd/parallel.py).
+// Length of the first member / raw length of all members.
+u64 bfq_codec_member_len(const u8 *h_in, u64 len)
+{
+    CdcHeader H;
+    cdc_parse(h_in, len, H);
+    u64 total = H.hdr;
+    for (u32 g = 0; g < H.m.nseg; g++) total += H.segBytes[g];
+    return total;
+}
 u64 bfq_codec_raw_len(const u8 *h_in, u64 len)
 {
-    if (len < 36 + 256 || memcmp(h_in, "BFQRANS1", 8)) throw BfqError{BFQ_E_ARG, "not a BFQRANS1 stream"};
-    return get64(h_in + 8);
+    u64 pos = 0, raw = 0;
+    do {
+        if (len - pos < 36 + 256 || memcmp(h_in + pos, "BFQRANS1", 8)) throw BfqError{BFQ_E_ARG, "not a BFQRANS1 stream"};
+        raw += get64(h_in + pos + 8);
+        pos += bfq_codec_member_len(h_in + pos, len - pos);
+    } while (pos < len);
+    return raw;
 }
 
 // h_in: the whole container on the host (its header is parsed there), d_in: the same bytes on the device.

@@ -176,9 +176,12 @@ KINDS = ("fastq", "dna", "qs", "hdr")
 
 
 def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fastq=True, want_streams=False,
-              want_hdr=False, out_bufs=None, log=None):
+              want_hdr=False, out_bufs=None, log=None, compress=False):
     """The whole multi-GPU job.  eng: Engine-like (fastq_job, text_line_counts/text_nth_newline via `eng.host`).
-    Returns per-rank totals {"blocks", "reads", "bases", "stats"} (stats summed over this rank's blocks)."""
+    Returns per-rank totals {"blocks", "reads", "bases", "stats"} (stats summed over this rank's blocks).
+    compress: step 5 too (BFQzip.py:253-275) -- every block's share of every output goes through the stream codec
+    (eng.stream_compress) and the files `<name>.bsc` hold one BFQRANS1 container per block, in block order
+    (`bsc d` / stream_decompress read them back as one stream)."""
     host = eng.host
     bufs = [map_file(p) for p in inputs]
     idx = [TextIndex(b, comm, host.text_line_counts, host.text_nth_newline) for b in bufs]
@@ -186,6 +189,8 @@ def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fas
     nblocks = len(blocks[0])                                         # the blocks of file 1 drive the run (:97-119)
     kinds = [k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w]
     nout = 2 if paired else 1
+    if compress:
+        names = [{k: v + ".bsc" for k, v in nm.items()} for nm in names]
     if comm.rank == 0:                                               # create / truncate the outputs once
         for o in range(nout):
             for k in kinds:
@@ -210,12 +215,17 @@ def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fas
                                 out=out_bufs)
             cut = {"fastq": res.part_fastq_off, "dna": res.part_stream_off, "qs": res.part_stream_off,
                    "hdr": res.part_hdr_off}
+            raw = {"fastq": res.fastq, "dna": res.dna, "qs": res.qs, "hdr": res.hdr}
+            blobs = {}
             for o in range(nout):
                 for ki, kind in enumerate(KINDS):
                     if kind in kinds:
                         lo = cut[kind][o] if o < len(parts) else cut[kind][-1]
                         hi = cut[kind][o + 1] if o < len(parts) else cut[kind][-1]
                         sizes[o, ki] = hi - lo
+                        if compress:                                 # this mate's share of the block as one container
+                            blobs[(o, kind)] = eng.stream_compress(raw[kind][lo:hi])
+                            sizes[o, ki] = len(blobs[(o, kind)])
             tot["blocks"] += 1; tot["reads"] += res.n_reads; tot["bases"] += res.total_bases
             for key, v in res.stats.items():
                 if key.startswith("n_"):
@@ -231,7 +241,8 @@ def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fas
                 for ki, kind in enumerate(KINDS):
                     if kind in kinds and sizes[o, ki]:
                         lo = cut[kind][o]
-                        pwrite_all(fds[(o, kind)], data[kind][lo:lo + int(sizes[o, ki])], int(cursor[o, ki] + before[o, ki]))
+                        piece = blobs[(o, kind)] if compress else data[kind][lo:lo + int(sizes[o, ki])]
+                        pwrite_all(fds[(o, kind)], piece, int(cursor[o, ki] + before[o, ki]))
         cursor += allsz.sum(axis=0)[:nout]
     for fd in fds.values():
         os.close(fd)
@@ -377,7 +388,9 @@ def main(argv=None):
     ap.add_argument("-T", "--mcl", default="", help="minimum context length (bfq_int -k)")
     ap.add_argument("-Q", "--rv", default="", help="constant replacement value (bfq_int -v)")
     ap.add_argument("-H", "--headers", action="store_true", help="store original headers")
-    ap.add_argument("-0", "--m0", action="store_true", help="do not compress (always the case: step 5 is out of scope)")
+    ap.add_argument("-0", "--m0", action="store_true", help="do not compress (the default here; see --compress)")
+    ap.add_argument("--compress", action="store_true",
+                    help="step 5 on the GPU: every output goes through the stream codec, files get the suffix .bsc (one container per block)")
     ap.add_argument("-p", "--paired", action="store_true")
     ap.add_argument("-t", "--threads", type=int, default=0, help="number of blocks")
     ap.add_argument("-c", "--check", action="store_true", help="accepted: records are always checked on the GPU")
@@ -429,7 +442,8 @@ def main(argv=None):
                          want_streams=streams, want_hdr=a.m3, log=log)
     else:
         tot = run_files(eng, comm, a.input, a.threads, names, paired=a.paired, headers=a.headers,
-                        want_fastq=not (streams and a.streams_only), want_streams=streams, want_hdr=a.m3, out_bufs=bufs, log=log)
+                        want_fastq=not (streams and a.streams_only), want_streams=streams, want_hdr=a.m3, out_bufs=bufs, log=log,
+                        compress=a.compress and not a.m0)
     if a.v:
         print(f"[rank {comm.rank}] {tot}", flush=True)
     eng.close()

@@ -189,6 +189,25 @@ int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t c
     return ret;
 }
 
+/* bytes of the first container of a buffer that may hold several back to back (-1: not one) */
+int64_t orc_codec_member_len(const uint8_t *in, uint64_t len)
+{
+    if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
+    const uint32_t nseg = get32(in + 20), A = get32(in + 24), k = get32(in + 28);
+    if (A == 0 || A > 256 || k > 8) return -1;
+    uint64_t nctx = 1;
+    for (uint32_t j = 0; j < k; j++) { nctx *= A; if (nctx > (1u << 22)) return -1; }
+    uint64_t pos = 36 + 256 + 2ull * A;
+    if (pos + (nctx + 7) / 8 > len) return -1;
+    uint64_t nused = 0;
+    for (uint64_t c = 0; c < nctx; c++) nused += (in[pos + (c >> 3)] >> (c & 7)) & 1;
+    pos += (nctx + 7) / 8 + nused * A * 2;
+    if (pos + 4ull * nseg > len) return -1;
+    uint64_t total = pos + 4ull * nseg;
+    for (uint32_t g = 0; g < nseg; g++) total += get32(in + pos + 4ull * g);
+    return total <= len ? (int64_t)total : -1;
+}
+
 /* raw length of a container (-1: not one) */
 int64_t orc_codec_raw_len(const uint8_t *in, uint64_t len)
 {

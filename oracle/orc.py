@@ -114,15 +114,26 @@ def codec_encode(data):
 
 
 def codec_decode(blob):
+    """All members of a buffer (one container, or several back to back as the sharded driver writes them)."""
     blob = np.ascontiguousarray(blob, np.uint8)
     L = lib()
     L.orc_codec_decode.restype = C.c_int64
     L.orc_codec_raw_len.restype = C.c_int64
-    n = L.orc_codec_raw_len(_p(blob), C.c_uint64(len(blob)))
-    if n < 0:
-        raise RuntimeError("not a BFQRANS1 stream")
-    out = np.empty(max(int(n), 1), np.uint8)
-    r = L.orc_codec_decode(_p(blob), C.c_uint64(len(blob)), _p(out), C.c_uint64(n))
-    if r != n:
-        raise RuntimeError("orc_codec_decode failed: %d" % r)
-    return out[:n]
+    L.orc_codec_member_len.restype = C.c_int64
+    outs = []
+    pos = 0
+    while True:
+        part = blob[pos:]
+        ml = L.orc_codec_member_len(_p(part), C.c_uint64(len(part)))
+        n = L.orc_codec_raw_len(_p(part), C.c_uint64(len(part)))
+        if ml < 0 or n < 0:
+            raise RuntimeError("not a BFQRANS1 stream")
+        out = np.empty(max(int(n), 1), np.uint8)
+        r = L.orc_codec_decode(_p(part), C.c_uint64(ml), _p(out), C.c_uint64(n))
+        if r != n:
+            raise RuntimeError("orc_codec_decode failed: %d" % r)
+        outs.append(out[:n])
+        pos += int(ml)
+        if pos >= len(blob):
+            break
+    return outs[0] if len(outs) == 1 else np.concatenate(outs)

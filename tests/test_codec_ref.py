@@ -60,6 +60,13 @@ def test_sampled_model_codes_what_the_sample_missed():
     assert len(blob) < 0.245 * len(data)          # entropy of the source: 1.85 bits per symbol
 
 
+def test_members_back_to_back():
+    c = cases()
+    parts = [c["dna_like"], c["empty"], c["headers"], c["one_byte"]]
+    blob = np.concatenate([orc.codec_encode(p) for p in parts])
+    assert (orc.codec_decode(blob) == np.concatenate(parts)).all()
+
+
 def test_damaged_streams_are_refused():
     blob = orc.codec_encode(cases()["dna_like"])
     with pytest.raises(RuntimeError):

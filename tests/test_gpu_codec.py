@@ -108,6 +108,14 @@ def test_sampled_model(engine):
     assert (np.asarray(engine.stream_decompress(blob)) == data).all()
 
 
+def test_members_back_to_back(engine):
+    """What the sharded driver writes: one container per block, concatenated."""
+    c = cases()
+    parts = [c["dna_like"], c["headers"], c["smoothed_qs_like"], c["one_byte"]]
+    blob = np.concatenate([np.asarray(engine.stream_compress(p)) for p in parts])
+    assert (np.asarray(engine.stream_decompress(blob)) == np.concatenate(parts)).all()
+
+
 def test_refuses_damaged_streams(engine):
     blob = np.asarray(engine.stream_compress(cases()["dna_like"])).copy()
     with pytest.raises(api.BfqError):

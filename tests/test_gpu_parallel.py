@@ -50,6 +50,23 @@ def test_streams_headers_and_paired(tmp_path):
         assert hashlib.md5(b"".join((b"@" if i % 4 == 0 else x) + b"\n" for i, x in enumerate(fq))).hexdigest() == md
 
 
+def test_step_5_in_the_sharded_run(orc, tmp_path):
+    """--compress over 2 ranks: `<name>.bsc` = one BFQRANS1 container per block in block order; decoded (CPU statement and
+    GPU codec) they are the files of the run without step 5."""
+    from bfqzip_amd import api
+    f1, f2 = paired_inputs(str(tmp_path))
+    plain, z = str(tmp_path / "P"), str(tmp_path / "Z")
+    _launch(2, [f1, f2, "-p", "-o", plain, "-t", "3", "--m3"], str(tmp_path))
+    _launch(2, [f1, f2, "-p", "-o", z, "-t", "3", "--m3", "--compress"], str(tmp_path))
+    eng = api.Engine()
+    for suffix in ("_1.fastq", "_1.fastq.dna", "_1.fastq.qs", "_1.h", "_2.fastq", "_2.fastq.qs", "_2.h"):
+        want = open(plain + suffix, "rb").read()
+        blob = np.frombuffer(open(z + suffix + ".bsc", "rb").read(), np.uint8)
+        assert orc.codec_decode(blob).tobytes() == want, suffix
+        assert np.asarray(eng.stream_decompress(blob)).tobytes() == want, suffix
+    eng.close()
+
+
 def _synth_fastq(path, spec_seed, n_reads, L, tag):
     """Seeded synthetic reads as a FASTQ file with distinct header lines of varying length."""
     from bfqzip_amd import api, fastq

@@ -68,6 +68,23 @@ def test_output_names_follow_the_reference():
     assert [x["fastq"] for x in n] == ["a.cat.fastq", "b.cat.fastq"]          # BFQzip_parallel.py:142-147
 
 
+def test_sharded_run_with_step_5(orc, tmp_path):
+    """--compress: every block's share of every output as one BFQRANS1 container, the files `<name>.bsc` hold them in block
+    order and decode to what the run without step 5 writes (paired: the mates' shares are coded separately)."""
+    eng = util.OracleEngine(orc, m=5)
+    f1, f2 = paired_inputs(str(tmp_path))
+    plain = parallel.output_names([f1, f2], str(tmp_path / "P"), True)
+    parallel.run_files(eng, parallel.Comm(), [f1, f2], 3, plain, paired=True, headers=True, want_streams=True, want_hdr=True)
+    z = parallel.output_names([f1, f2], str(tmp_path / "Z"), True)
+    parallel.run_files(eng, parallel.Comm(), [f1, f2], 3, z, paired=True, headers=True, want_streams=True, want_hdr=True, compress=True)
+    for o in range(2):
+        for kind in ("fastq", "dna", "qs", "hdr"):
+            blob = np.frombuffer(open(z[o][kind] + ".bsc", "rb").read(), np.uint8)
+            assert blob[:8].tobytes() == b"BFQRANS1"
+            assert orc.codec_decode(blob).tobytes() == open(plain[o][kind], "rb").read(), (o, kind)
+            assert not os.path.exists(z[o][kind])
+
+
 @pytest.mark.parametrize("t", [2, 8])
 def test_sharded_output_equals_reference_parallel_run(orc, t, tmp_path):
     eng = util.OracleEngine(orc, m=5)

@@ -69,6 +69,9 @@ class OracleEngine:
         self.orc, self.p = orc, orc.params(**params)
         self.host = api.HostText
 
+    def stream_compress(self, data, out=None):
+        return self.orc.codec_encode(np.ascontiguousarray(data, np.uint8))
+
     def fastq_job(self, parts, keep_headers=False, fastq=True, streams=False, hdr=False, out=None):
         from bfqzip_amd import api, fastq as fqm
         texts = []
