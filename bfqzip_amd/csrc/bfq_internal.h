@@ -164,6 +164,8 @@ void bfq_exscan_u8(bfq_ctx *c, const u8 *in, u64 *out, u64 n, u64 *d_total);
 void bfq_exscan_u32(bfq_ctx *c, const u32 *in, u64 *out, u64 n, u64 *d_total);
 void bfq_exscan_u64(bfq_ctx *c, const u64 *in, u64 *out, u64 n, u64 *d_total);
 
+u64 *bfq_line_index(bfq_ctx *c, const u8 *d_buf, u64 len, u64 *nlines);   // k_fastq.hip: positions of the line ends (arena)
+u64 bfq_fastq_count_lines(bfq_ctx *c, const u8 *d_buf, u64 len);          // k_fastq.hip: newlines + 1
 // stream codec (k_codec.hip)
 u64 bfq_codec_bound(u64 n);
 u64 bfq_codec_workspace(u64 n);

@@ -338,17 +338,18 @@ static u64 get64(const u8 *p) { return (u64)get32(p) | ((u64)get32(p + 4) << 32)
 u64 bfq_codec_bound(u64 n)
 {
     const u64 nseg = (n + 1023) / 1024;
-    return 36 + 256 + 512 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64;
+    return 32 + 36 + 256 + 512 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64;
 }
 // device workspace of one compress / decompress call
 u64 bfq_codec_workspace(u64 n)
 {
     const u64 nseg = (n + 1023) / 1024;
-    return n + bfq_codec_bound(n) + nseg * (u64)CQ_SLOT(1024) + 16ull * CQ_MAX_TABLE + 24 * nseg + (64u << 20);
+    // + the line-delta transform of streams with 8 .. 128 bytes per line: line index, prefix lengths, record sizes / offsets, the records
+    return n + bfq_codec_bound(n) + nseg * (u64)CQ_SLOT(1024) + 16ull * CQ_MAX_TABLE + 24 * nseg + 4 * n + (64u << 20);
 }
 
 // d_in: n raw bytes on the device.  The container goes to d_out (capacity cap); returns its length.
-u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
+static u64 rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
 {
     const size_t mk = c->mark();
     u32 *d_present = c->alloc<u32>(256);
@@ -481,6 +482,7 @@ static void cdc_parse(const u8 *in, u64 len, CdcHeader &H)
 // Length of the first member / raw length of all members.
 u64 bfq_codec_member_len(const u8 *h_in, u64 len)
 {
+    if (len >= 32 && !memcmp(h_in, "BFQLINE1", 8)) return 32 + bfq_codec_member_len(h_in + 32, len - 32);
     CdcHeader H;
     cdc_parse(h_in, len, H);
     u64 total = H.hdr;
@@ -491,7 +493,8 @@ u64 bfq_codec_raw_len(const u8 *h_in, u64 len)
 {
     u64 pos = 0, raw = 0;
     do {
-        if (len - pos < 36 + 256 || memcmp(h_in + pos, "BFQRANS1", 8)) throw BfqError{BFQ_E_ARG, "not a BFQRANS1 stream"};
+        const bool lx = len - pos >= 32 && !memcmp(h_in + pos, "BFQLINE1", 8);
+        if (!lx && (len - pos < 36 + 256 || memcmp(h_in + pos, "BFQRANS1", 8))) throw BfqError{BFQ_E_ARG, "not a BFQRANS1 stream"};
         raw += get64(h_in + pos + 8);
         pos += bfq_codec_member_len(h_in + pos, len - pos);
     } while (pos < len);
@@ -500,7 +503,7 @@ u64 bfq_codec_raw_len(const u8 *h_in, u64 len)
 
 // h_in: the whole container on the host (its header is parsed there), d_in: the same bytes on the device.
 // The raw bytes go to d_out (capacity cap); returns their number.
-u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap)
+static u64 rans_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap)
 {
     CdcHeader H;
     cdc_parse(h_in, len, H);
@@ -537,4 +540,159 @@ u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 
     c->release(mk);
     if (bad) throw BfqError{BFQ_E_ARG, "damaged BFQRANS1 stream"};
     return m.n;
+}
+
+// ---- line-delta transform of line-structured streams (read names): oracle/bfq_codec_ref.c states it ---------------------
+#define CQ_LINE_R 256u
+// p[i] = bytes line i shares with the line before (0 for every R-th line; at most 254 and the line's length - 1),
+// sizes[i] = 1 + length - p[i] = bytes of its record.  One lane per line, 8 bytes per comparison.
+__global__ __launch_bounds__(256) void k_lx_sizes(const u8 *__restrict__ in, const u64 *__restrict__ lineEnd, u64 nl,
+                                                  u8 *__restrict__ pfx, u32 *__restrict__ sizes)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += (u64)gridDim.x * blockDim.x) {
+        const u64 s = i ? lineEnd[i - 1] + 1 : 0, len = lineEnd[i] - s + 1;
+        u64 p = 0;
+        if (i % CQ_LINE_R) {
+            const u64 ps = i >= 2 ? lineEnd[i - 2] + 1 : 0, plen = s - ps;
+            u64 lim = len - 1;
+            if (lim > plen) lim = plen;
+            if (lim > 254) lim = 254;
+            while (p + 8 <= lim) {
+                u64 a, b;
+                __builtin_memcpy(&a, in + s + p, 8); __builtin_memcpy(&b, in + ps + p, 8);
+                const u64 x = a ^ b;
+                if (x) { p += (u64)(__builtin_ctzll(x) >> 3); lim = p; break; }
+                p += 8;
+            }
+            while (p < lim && in[s + p] == in[ps + p]) p++;
+        }
+        pfx[i] = (u8)p;
+        sizes[i] = (u32)(1 + len - p);
+    }
+}
+__global__ __launch_bounds__(256) void k_lx_write(const u8 *__restrict__ in, const u64 *__restrict__ lineEnd, u64 nl,
+                                                  const u8 *__restrict__ pfx, const u64 *__restrict__ off, u8 *__restrict__ out)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += (u64)gridDim.x * blockDim.x) {
+        const u64 s = i ? lineEnd[i - 1] + 1 : 0, e = lineEnd[i];
+        const u32 p = pfx[i];
+        u8 *o = out + off[i];
+        *o++ = (u8)(p + (p >= 10u ? 1u : 0u));
+        for (u64 j = s + p; j <= e; j++) *o++ = in[j];
+    }
+}
+// inverse: length of every line from its record; then the lines of a group of R one after the other (a lane per group)
+__global__ __launch_bounds__(256) void k_lxi_len(const u8 *__restrict__ t, const u64 *__restrict__ recEnd, u64 nl, u32 *__restrict__ lens,
+                                                 u32 *__restrict__ bad)
+{
+    for (u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x; i < nl; i += (u64)gridDim.x * blockDim.x) {
+        const u64 rs = i ? recEnd[i - 1] + 1 : 0;
+        u32 p = t[rs];
+        if (p == 10u || rs == recEnd[i]) atomicAdd(bad, 1u);      // a record starts with its prefix byte, never with the line end
+        if (p > 10u) p--;
+        if (p && i % CQ_LINE_R == 0) atomicAdd(bad, 1u);
+        lens[i] = p + (u32)(recEnd[i] - rs);
+    }
+}
+__global__ __launch_bounds__(256) void k_lxi_write(const u8 *__restrict__ t, const u64 *__restrict__ recEnd, u64 nl,
+                                                   const u64 *__restrict__ outOff, u8 *__restrict__ out, u32 *__restrict__ bad)
+{
+    const u64 ngroups = (nl + CQ_LINE_R - 1) / CQ_LINE_R;
+    for (u64 g = (u64)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (u64)gridDim.x * blockDim.x) {
+        const u64 i0 = g * CQ_LINE_R, i1 = (i0 + CQ_LINE_R < nl) ? i0 + CQ_LINE_R : nl;
+        u64 prev = 0, prevLen = 0;
+        for (u64 i = i0; i < i1; i++) {
+            const u64 rs = i ? recEnd[i - 1] + 1 : 0, re = recEnd[i];
+            u32 p = t[rs];
+            if (p > 10u) p--;
+            if (p > prevLen) { atomicAdd(bad, 1u); p = (u32)prevLen; }
+            u8 *o = out + outOff[i];
+            for (u32 j = 0; j < p; j++) o[j] = out[prev + j];
+            for (u64 j = rs + 1; j <= re; j++) o[p + (j - rs - 1)] = t[j];
+            prev = outOff[i]; prevLen = p + (re - rs);
+        }
+    }
+}
+
+// transformed stream of d_in (arena) and its length, or 0 when the transform does not apply / does not pay
+static u64 line_xform_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 **d_T, u64 *nlines)
+{
+    if (n < 2) return 0;
+    u8 last = 0;
+    HIP_CHECK(hipMemcpyAsync(&last, d_in + n - 1, 1, hipMemcpyDeviceToHost, c->stream));
+    const u64 nl = bfq_fastq_count_lines(c, d_in, n) - 1;        // (synchronises)
+    if (last != 10 || nl < 2 || n / nl < 8 || n / nl > 128) return 0;
+    u64 nl2 = 0;
+    const u64 *lineEnd = bfq_line_index(c, d_in, n, &nl2);
+    u8 *pfx = c->alloc<u8>(nl);
+    u32 *sizes = c->alloc<u32>(nl);
+    u64 *off = c->alloc<u64>(nl + 1), *d_total = c->alloc<u64>(1);
+    KLAUNCH(c, K_CODEC, 2.0 * (double)n, k_lx_sizes, bfq_grid(nl, 256), 256, d_in, lineEnd, nl, pfx, sizes);
+    bfq_exscan_u32(c, sizes, off, nl, d_total);
+    u64 total = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (total * 4 > n * 3) return 0;
+    *d_T = c->alloc<u8>(total + 16);
+    KLAUNCH(c, K_CODEC, (double)n + (double)total, k_lx_write, bfq_grid(nl, 256), 256, d_in, lineEnd, nl, (const u8 *)pfx, (const u64 *)off, *d_T);
+    *nlines = nl;
+    return total;
+}
+
+// d_in: n raw bytes on the device.  The container goes to d_out (capacity cap); returns its length.
+u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
+{
+    const size_t mk = c->mark();
+    u8 *d_T = nullptr;
+    u64 nl = 0;
+    const u64 xl = line_xform_device(c, d_in, n, &d_T, &nl);
+    u64 got;
+    if (!xl) got = rans_compress_device(c, d_in, n, d_out, cap);
+    else {
+        if (cap < 32) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
+        u8 h[32];
+        memcpy(h, "BFQLINE1", 8); put64(h + 8, n); put32(h + 16, CQ_LINE_R); put32(h + 20, 0); put64(h + 24, nl);
+        HIP_CHECK(hipMemcpyAsync(d_out, h, 32, hipMemcpyHostToDevice, c->stream));
+        c->sync();
+        got = 32 + rans_compress_device(c, d_T, xl, d_out + 32, cap - 32);
+    }
+    c->release(mk);
+    return got;
+}
+
+// h_in: the whole container on the host (its header is parsed there), d_in: the same bytes on the device.
+// The raw bytes go to d_out (capacity cap); returns their number.
+u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap)
+{
+    if (len < 32 || memcmp(h_in, "BFQLINE1", 8)) return rans_decompress_device(c, h_in, d_in, len, d_out, cap);
+    const BfqError bad{BFQ_E_ARG, "damaged BFQLINE1 stream"};
+    const u64 n = get64(h_in + 8), nl = get64(h_in + 24);
+    if (n > cap || get32(h_in + 16) != CQ_LINE_R || nl < 2 || nl > n) throw bad;
+    if (len - 32 < 36 + 256 || memcmp(h_in + 32, "BFQRANS1", 8)) throw bad;
+    const u64 xl = get64(h_in + 32 + 8);
+    if (xl > n + nl) throw bad;
+    const size_t mk = c->mark();
+    u8 *d_T = c->alloc<u8>(xl + 16);
+    if (rans_decompress_device(c, h_in + 32, d_in + 32, len - 32, d_T, xl) != xl) throw bad;
+    u64 nrec = 0;
+    const u64 *recEnd = bfq_line_index(c, d_T, xl, &nrec);
+    if (nrec != nl) throw bad;
+    u32 *lens = c->alloc<u32>(nl), *d_bad = c->alloc<u32>(1);
+    u64 *off = c->alloc<u64>(nl + 1), *d_total = c->alloc<u64>(1);
+    HIP_CHECK(hipMemsetAsync(d_bad, 0, 4, c->stream));
+    KLAUNCH(c, K_CODEC, (double)xl, k_lxi_len, bfq_grid(nl, 256), 256, (const u8 *)d_T, recEnd, nl, lens, d_bad);
+    bfq_exscan_u32(c, lens, off, nl, d_total);
+    u64 total = 0;
+    u32 nbad = 0;
+    HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_CHECK(hipMemcpyAsync(&nbad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    if (nbad || total != n) throw bad;
+    KLAUNCH(c, K_CODEC, (double)xl + (double)n, k_lxi_write, bfq_grid((nl + CQ_LINE_R - 1) / CQ_LINE_R, 256), 256, (const u8 *)d_T, recEnd, nl,
+            (const u64 *)off, d_out, d_bad);
+    HIP_CHECK(hipMemcpyAsync(&nbad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    c->release(mk);
+    if (nbad) throw bad;
+    return n;
 }

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void k_fq_hdr_gather(const u8 *__restrict__ bu
 
 // positions of the line ends of a text resident on the device; a last line without newline gets a
 // virtual end at `len`.  *nlines = number of lines.
-static u64 *line_index(bfq_ctx *c, const u8 *d_buf, u64 len, u64 *nlines)
+u64 *bfq_line_index(bfq_ctx *c, const u8 *d_buf, u64 len, u64 *nlines)
 {
     u64 nchunks = ceil_div(len ? len : 1, NL_CHUNK);
     u32 *counts = c->alloc<u32>(nchunks);
@@ -218,7 +218,7 @@ u64 bfq_fastq_count_lines(bfq_ctx *c, const u8 *d_buf, u64 len)
 void bfq_fastq_parse(bfq_ctx *c, const u8 *d_fastq, u64 len, DevFastq *fq)
 {
     u64 nlines = 0;
-    u64 *lineEnd = line_index(c, d_fastq, len, &nlines);
+    u64 *lineEnd = bfq_line_index(c, d_fastq, len, &nlines);
     if (nlines % 4) throw BfqError{BFQ_E_ARG, "FASTQ: number of lines is not a multiple of 4"};
     u64 N = nlines / 4;
     fq->N = N;
@@ -254,7 +254,7 @@ u64 bfq_fastq_format(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
         hLen = c->alloc<u32>(N + 1);
         if (mode == 1) {
             u64 nl = 0;
-            const u64 *hdrEnd = line_index(c, d_hdr, hdrLen, &nl);
+            const u64 *hdrEnd = bfq_line_index(c, d_hdr, hdrLen, &nl);
             if (nl < N) throw BfqError{BFQ_E_ARG, "header file has fewer lines than there are reads"};
             if (N) KLAUNCH(c, K_FASTQ, 20.0 * (double)N, k_fq_hdr_from_lines, bfq_grid(N, 256), 256, hdrEnd, N, hStart, hLen);
         } else if (N) {

@@ -7,6 +7,13 @@
  * chosen for the GPU: a static order-k model per stream + range-ANS (Duda's rANS, byte-wise renormalisation), every
  * segment of 8192 symbols coded on its own so that encoder and decoder run one segment per lane.
  *
+ * Line-structured streams (read names) first go through a LINE-DELTA transform when that shrinks them to 3/4 or less:
+ *   char magic[8] = "BFQLINE1" | u64 raw_len | u32 R (= 256) | u32 0 | u64 number of lines | one BFQRANS1 container of the
+ *   transformed bytes: per line (bytes up to and including its '\n'; the stream must end with one) a record
+ *   byte(p + (p >= 10)) + line[p:], p = 0 for every R-th line, else the length of the prefix shared with the line before,
+ *   capped at 254 and at the line's length - 1 (the record keeps the line's '\n', and no other byte of it is a '\n').
+ * A file may hold several containers of either kind back to back (one per block of a sharded run).
+ *
  * Container (little endian):
  *   char  magic[8] = "BFQRANS1"
  *   u64   raw_len
@@ -93,7 +100,7 @@ static void normalise(const uint32_t *cnt, uint32_t A, uint16_t *f)
 }
 
 /* returns the container's length, -1 when `cap` is too small, -2 on allocation failure */
-int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap)
+static int64_t rans_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap)
 {
     uint32_t present[256] = {0}, map[256] = {0};
     for (uint64_t i = 0; i < n; i++) present[in[i]] = 1;
@@ -192,6 +199,7 @@ int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t c
 /* bytes of the first container of a buffer that may hold several back to back (-1: not one) */
 int64_t orc_codec_member_len(const uint8_t *in, uint64_t len)
 {
+    if (len >= 32 && !memcmp(in, "BFQLINE1", 8)) { int64_t r = orc_codec_member_len(in + 32, len - 32); return r < 0 ? -1 : r + 32; }
     if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
     const uint32_t nseg = get32(in + 20), A = get32(in + 24), k = get32(in + 28);
     if (A == 0 || A > 256 || k > 8) return -1;
@@ -211,12 +219,13 @@ int64_t orc_codec_member_len(const uint8_t *in, uint64_t len)
 /* raw length of a container (-1: not one) */
 int64_t orc_codec_raw_len(const uint8_t *in, uint64_t len)
 {
+    if (len >= 32 && !memcmp(in, "BFQLINE1", 8)) return (int64_t)get64(in + 8);
     if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
     return (int64_t)get64(in + 8);
 }
 
 /* returns raw_len, -1 on a malformed container / short `cap` */
-int64_t orc_codec_decode(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t cap)
+static int64_t rans_decode(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t cap)
 {
     if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
     const uint64_t n = get64(in + 8);
@@ -273,5 +282,75 @@ int64_t orc_codec_decode(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t
         pay += bytes;
     }
     free(freq); free(cum);
+    return ret;
+}
+
+/* ---- line-delta transform -------------------------------------------------------------------------------------- */
+#define BQC_LINE_R 256u
+/* transformed length, or 0 when the stream is not made of '\n'-terminated lines (or has fewer than two) */
+static uint64_t line_xform(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t *nlines)
+{
+    if (n < 2 || in[n - 1] != '\n') return 0;
+    uint64_t o = 0, prev = 0, prevLen = 0, i = 0, ln = 0;
+    while (i < n) {
+        uint64_t e = i;
+        while (in[e] != '\n') e++;
+        const uint64_t len = e - i + 1;
+        uint64_t p = 0;
+        if (ln % BQC_LINE_R) {
+            uint64_t lim = len - 1;
+            if (lim > prevLen) lim = prevLen;
+            if (lim > 254) lim = 254;
+            while (p < lim && in[i + p] == in[prev + p]) p++;
+        }
+        if (out) { out[o] = (uint8_t)(p + (p >= 10)); memcpy(out + o + 1, in + i + p, len - p); }
+        o += 1 + len - p;
+        prev = i; prevLen = len; i = e + 1; ln++;
+    }
+    *nlines = ln;
+    return (ln >= 2 && n / ln >= 8 && n / ln <= 128) ? o : 0;   /* read names: lines of 8 .. 128 bytes on average */
+}
+
+int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap)
+{
+    uint64_t nl = 0;
+    const uint64_t xl = line_xform(in, n, NULL, &nl);
+    if (!xl || xl * 4 > n * 3) return rans_encode(in, n, out, cap);
+    if (cap < 32) return -1;
+    uint8_t *t = (uint8_t *)malloc(xl);
+    if (!t) return -2;
+    line_xform(in, n, t, &nl);
+    memcpy(out, "BFQLINE1", 8); put64(out + 8, n); put32(out + 16, BQC_LINE_R); put32(out + 20, 0); put64(out + 24, nl);
+    const int64_t r = rans_encode(t, xl, out + 32, cap - 32);
+    free(t);
+    return r < 0 ? r : r + 32;
+}
+
+int64_t orc_codec_decode(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t cap)
+{
+    if (len < 32 || memcmp(in, "BFQLINE1", 8)) return rans_decode(in, len, out, cap);
+    const uint64_t n = get64(in + 8), nl = get64(in + 24);
+    const uint32_t R = get32(in + 16);
+    if (n > cap || R == 0) return -1;
+    const int64_t xl = orc_codec_raw_len(in + 32, len - 32);
+    if (xl < 0) return -1;
+    uint8_t *t = (uint8_t *)malloc((size_t)xl + 1);
+    if (!t) return -1;
+    int64_t ret = (int64_t)n;
+    if (rans_decode(in + 32, len - 32, t, (uint64_t)xl) != xl) ret = -1;
+    uint64_t i = 0, o = 0, prev = 0, ln = 0;
+    while (ret >= 0 && i < (uint64_t)xl) {
+        uint64_t p = t[i];
+        if (p == 10) { ret = -1; break; }
+        if (p > 10) p--;
+        uint64_t e = i + 1;
+        while (e < (uint64_t)xl && t[e] != '\n') e++;
+        if (e >= (uint64_t)xl || o + p + (e - i) > n || (p && (ln % R == 0 || prev + p > o))) { ret = -1; break; }
+        memmove(out + o, out + prev, p);
+        memcpy(out + o + p, t + i + 1, e - i);
+        prev = o; o += p + (e - i); i = e + 1; ln++;
+    }
+    if (ret >= 0 && (o != n || ln != nl)) ret = -1;
+    free(t);
     return ret;
 }

@@ -57,7 +57,7 @@ def test_job_with_compressed_streams(engine):
     assert z.stats == plain.stats and np.array_equal(z.fastq, plain.fastq)
     for a, b in ((z.dna, plain.dna), (z.qs, plain.qs), (z.hdr, plain.hdr)):
         a = np.asarray(a)
-        assert bytes(a[:8]) == b"BFQRANS1" and len(a) < len(b)
+        assert bytes(a[:8]) in (b"BFQRANS1", b"BFQLINE1") and len(a) < len(b)
         assert np.array_equal(np.asarray(engine.stream_decompress(a)), np.asarray(b))
         assert np.array_equal(orc.codec_encode(np.asarray(b)), a)
     # two parts (paired blocks): the containers cover the whole collection
@@ -106,6 +106,29 @@ def test_sampled_model(engine):
     want = orc.codec_encode(data)
     assert len(blob) == len(want) and (blob == want).all()
     assert (np.asarray(engine.stream_decompress(blob)) == data).all()
+
+
+def test_line_delta_transform(engine):
+    """Read names: the GPU transform + container equal the CPU statement's; long / short / unterminated lines stay plain."""
+    c = cases()
+    rng = np.random.default_rng(8)
+    names = np.frombuffer(b"".join(b"@A00123:45:HXXXX:1:1101:%d:%d 1:N:0:ACGT\n" % (1000 + i // 7, 2000 + (i * 37) % 9000)
+                                   for i in range(300000)), np.uint8)
+    ragged = np.frombuffer(b"".join(b"@" + bytes(rng.integers(97, 100, int(rng.integers(1, 60))).astype(np.uint8)) + b"\n"
+                                    for _ in range(20000)), np.uint8)
+    for data, kind in ((c["headers"], b"BFQLINE1"), (names, b"BFQLINE1"), (ragged, None), (c["dna_like"], b"BFQRANS1"),
+                       (np.frombuffer(b"ab\n" * 1000, np.uint8), b"BFQRANS1"), (np.frombuffer(b"@r1\n@r2", np.uint8), b"BFQRANS1"),
+                       (np.frombuffer((b"x" * 20 + b"\n") * 600, np.uint8), b"BFQLINE1")):
+        blob = np.asarray(engine.stream_compress(data))
+        want = orc.codec_encode(data)
+        assert len(blob) == len(want) and (blob == want).all()
+        if kind:
+            assert blob[:8].tobytes() == kind
+        assert (np.asarray(engine.stream_decompress(blob)) == data).all()
+    bad = np.asarray(engine.stream_compress(names)).copy()
+    bad[24] ^= 1                                                   # the line count of the wrapper
+    with pytest.raises(api.BfqError):
+        engine.stream_decompress(bad)
 
 
 def test_members_back_to_back(engine):
