@@ -185,6 +185,27 @@ def stream_codec(api, eng, outs, lens, N, L, log, with_cpu, text=None):
                                      "what": "bfq_fastq_run_job with compress_streams: FASTQ text (pinned) -> parse, eBWT, clusters, inversion, "
                                              "entropy coding, all on the GPU -> three BFQRANS1 containers (pinned); the raw streams never cross the bus"}
         log(f"fused steps 1-5: {dt * 1e3:.0f} ms")
+        # the same with eBWT-domain containers: rows of the edited eBWT instead of reads (no inversion on the compressing side)
+        eng.fastq_job([text], streams=True, hdr=True, fastq=False, out=zb, compress=2)
+        t0 = time.perf_counter()
+        z2 = eng.fastq_job([text], streams=True, hdr=True, fastq=False, out=zb, compress=2)
+        dt = time.perf_counter() - t0
+        nb = int(len(z2.dna) + len(z2.qs) + len(z2.hdr))
+        back = (api.PinnedBuffer(lens["dna"] + 64), api.PinnedBuffer(lens["qs"] + 64))
+        t0 = time.perf_counter()
+        d2, q2, nr = eng.ebwt_decode(z2.dna, z2.qs, out=(back[0].array, back[1].array))
+        dt2 = time.perf_counter() - t0
+        same2 = bool(nr == N and np.array_equal(d2, outs["dna"].array[:lens["dna"]]) and np.array_equal(q2, outs["qs"].array[:lens["qs"]]))
+        res["ebwt_domain"] = {"wall_ms": round(dt * 1e3, 1), "Mbases_per_s": round(N * L / 1e6 / dt, 1), "bytes_out": nb,
+                              "dna_container_bytes": int(len(z2.dna)), "qs_container_bytes": int(len(z2.qs)),
+                              "ratio_to_raw_streams": round(tot_raw / max(nb, 1), 2), "decode_wall_ms": round(dt2 * 1e3, 1),
+                              "decoded_streams_equal_e2e_host": same2,
+                              "what": "bfq_fastq_run_job with compress_streams = 2: FASTQ text -> eBWT, clusters, smoothing -> the ROWS of the edited "
+                                      "eBWT (symbols + the replaced rows' originals, qualities) through the codec, no inversion; "
+                                      "bfq_stream_ebwt_decode: containers -> LF table -> reads (OUT.fq.dna / OUT.fq.qs)"}
+        log(f"ebwt domain: {dt * 1e3:.0f} ms, {nb} bytes, decode {dt2 * 1e3:.0f} ms, equal {same2}")
+        for b in back:
+            b.free()
         for v in zo.values():
             v.free()
     res["total"] = {"raw_bytes": int(tot_raw), "compressed_bytes": int(tot_cmp), "ratio": round(tot_raw / max(tot_cmp, 1), 2),

@@ -22,7 +22,7 @@ SYMBOLS = [
     "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device", "bfq_synth_fastq",
     "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
     "bfq_stream_bound", "bfq_stream_raw_len", "bfq_stream_compress", "bfq_stream_decompress",
-    "bfq_stream_reserve", "bfq_stream_compress_device",
+    "bfq_stream_reserve", "bfq_stream_compress_device", "bfq_stream_ebwt_decode",
     "bfq_workspace_bytes", "bfq_version",
 ]
 
@@ -143,6 +143,7 @@ def lib():
         L.bfq_stream_compress.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
         L.bfq_stream_decompress.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
         L.bfq_stream_reserve.argtypes = [vp, u64]
+        L.bfq_stream_ebwt_decode.argtypes = [vp, vp, u64, vp, u64, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)]
         L.bfq_stream_compress_device.argtypes = [vp, vp, u64, vp, u64, C.POINTER(u64)]
         L.bfq_prof_enable.argtypes = [vp, C.c_int]
         L.bfq_prof_reset.argtypes = [vp]

@@ -231,7 +231,7 @@ class Engine:
             return b if b is not None else np.empty(size, np.uint8)
         J = _lib.FastqJob()
         J.parts = tp; J.nparts = np_; J.keep_headers = 1 if keep_headers else 0
-        J.compress_streams = 1 if compress else 0
+        J.compress_streams = int(compress)                     # 0 raw, 1 containers of the streams, 2 eBWT-domain containers
         bf = buf("fastq", fastq, inlen + 5 * np_ + 16)
         bd, bq = buf("dna", streams, inlen + 16), buf("qs", streams, inlen + 16)
         bh = buf("hdr", hdr, inlen + 16)
@@ -371,6 +371,18 @@ class Engine:
         ol = C.c_uint64(0)
         self._ck(self.L.bfq_stream_decompress(self.h, _ptr(blob), len(blob), _ptr(out), len(out), C.byref(ol)))
         return out[:int(ol.value)]
+
+    def ebwt_decode(self, bwtz, qsz, out=None):
+        """The line streams (dna, qs) of a pair of eBWT-domain containers (fastq_job(compress=2)); returns (dna, qs, n_reads)."""
+        bwtz, qsz = _u8(bwtz), _u8(qsz)
+        if len(bwtz) < 32 or bytes(bwtz[:8]) != b"BFQEBWT1":
+            raise BfqError(-1, "not a BFQEBWT1 stream")
+        n = int(np.frombuffer(bwtz[8:16].tobytes(), np.uint64)[0])
+        dna, qs = out if out is not None else (np.empty(n + 16, np.uint8), np.empty(n + 16, np.uint8))
+        sl, nr = C.c_uint64(0), C.c_uint64(0)
+        self._ck(self.L.bfq_stream_ebwt_decode(self.h, _ptr(bwtz), len(bwtz), _ptr(qsz), len(qsz), _ptr(dna), _ptr(qs),
+                                               min(len(dna), len(qs)), C.byref(sl), C.byref(nr)))
+        return dna[:int(sl.value)], qs[:int(sl.value)], int(nr.value)
 
     def stream_compress_device(self, d_in, n, d_out, cap):
         """Device-resident form (after stream_reserve(n)); returns the container's length."""

@@ -15,6 +15,7 @@
 #include "bfq_internal.h"
 #include "bfq_synth.h"
 #include "bfq_device.h"
+#include "bfq_rank.h"
 
 const char *const BFQ_KERNEL_NAMES[K_NUM] = {
     "k_text_from_reads", "k_pack3", "k_build_keys", "k_radix_hist", "k_scan", "k_radix_scatter", "k_huge_round",
@@ -376,7 +377,27 @@ static void invert_lines(bfq_ctx *c, const RankIndex &R, const u64 *d_roff, u8 *
     HIP_CHECK(hipStreamSynchronize(c->copyStream));
     for (int j = 0; j < C; j++) (void)hipEventDestroy(ev[j]);
 }
-static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals, u32 *lens = nullptr, const StreamOut *so = nullptr)
+// eBWT-domain output (bfq_fastq_job.compress_streams == 2): the rows of the eBWT as the cluster step left them -- symbol after
+// noise reduction, quality after smoothing (binned when B = 1; a constant at the terminator rows, whose quality byte never
+// reaches a FASTQ) -- instead of the reads they invert to.  In row order the symbols of a deep collection are runs: they
+// code to half the size of the read-order stream, and the compressing side skips the inversion altogether.
+struct EbwtOut { u8 *sym, *qual, *patch; };
+// patch[r] = the ORIGINAL symbol of a row whose base was replaced, else 0: the walk navigates by the original eBWT
+// (invert, bfq_int.cpp:782-790: base = replaced ? BWT_MOD : bwt[j], j = LF(j) of the unchanged BWT).
+__global__ __launch_bounds__(256) void k_ebwt_rows(const u64 *__restrict__ lfq, u64 n, u32 term, int B, u8 *__restrict__ sym, u8 *__restrict__ qual,
+                                                   u8 *__restrict__ patch)
+{
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x) {
+        const u64 x = lfq[r];
+        const u32 code = lfq_replaced(x) ? lfq_repl(x) : lfq_code(x);
+        sym[r] = code ? bfq_code_sym(code) : (u8)term;
+        patch[r] = lfq_replaced(x) ? bfq_code_sym(lfq_code(x)) : (u8)0;
+        const u32 q = lfq_qual(x);
+        qual[r] = lfq_code(x) ? (u8)(B ? bfq_bin8(q) : q) : (u8)'!';
+    }
+}
+static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_quals, u32 *lens = nullptr, const StreamOut *so = nullptr,
+                            const EbwtOut *eo = nullptr)
 {
     u64 n = c->n, N = c->N;
     if (!n) return;
@@ -391,6 +412,10 @@ static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_
     u8 *in = c->alloc<u8>(n + 64);
     bfq_lcp_flags(c, c->d_lcp, n, c->P.K, in);
     bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n);
+    if (eo) {
+        KLAUNCH(c, K_MISC, 10.0 * (double)n, k_ebwt_rows, bfq_grid(n, 256), 256, (const u64 *)R.lfq, n, (u32)(c->P.term & 0xFF), c->P.B, eo->sym, eo->qual, eo->patch);
+        return;
+    }
     if (so) { invert_lines(c, R, d_roff, d_out_bases, d_out_quals, so); return; }
     bfq_invert(c, R, N, d_roff, c->P.B, d_out_bases, d_out_quals);
     if (guessed) {
@@ -776,10 +801,13 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         bfq_fastq_parse(c, d_fq, len, &fq);
         J->n_reads = fq.N; J->total_bases = fq.total;
         const bool wantStreams = J->out_dna || J->out_qs || J->out_hdr;
+        const bool ebwtDomain = J->compress_streams == 2;          // rows of the edited eBWT instead of reads: no inversion on this side
+        if (ebwtDomain && (!J->out_dna || !J->out_qs || J->out_fastq)) throw BfqError{BFQ_E_ARG, "compress_streams = 2 gives out_dna and out_qs (no FASTQ text)"};
         const bool lines = J->out_dna || J->out_qs;               // the inversion writes the line streams itself
         const u64 sl = fq.total + fq.N;
         if (lines && sl > J->cap_stream) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
         u8 *ob = c->alloc<u8>((lines ? sl : fq.total) + 64), *oq = c->alloc<u8>((lines ? sl : fq.total) + 64);
+        u8 *op = ebwtDomain ? c->alloc<u8>(sl + 64) : nullptr;    // eBWT domain: the replaced rows' original symbols
         // per part: index of its first record, and where its share of every output starts (np + 1 entries each)
         u64 *d_pidx = c->alloc<u64>(np + 1), *d_pick = c->alloc<u64>(4 * (np + 1));
         bfq_fastq_part_index(c, &fq, ps.data(), np, d_pidx);
@@ -811,7 +839,8 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         size_t m = c->mark();
         bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
         StreamOut so{cz ? nullptr : J->out_dna, cz ? nullptr : J->out_qs};
-        steps234_device(c, fq.roff, ob, oq, nullptr, lines ? &so : nullptr);
+        EbwtOut eo{ob, oq, op};                                       // (n = total + N rows: the line-stream buffers have exactly that size)
+        steps234_device(c, fq.roff, ob, oq, nullptr, lines ? &so : nullptr, ebwtDomain ? &eo : nullptr);
         if (lines) { J->stream_len = sl; if (!cz) { J->dna_bytes = J->out_dna ? sl : 0; J->qs_bytes = J->out_qs ? sl : 0; } }
         c->release(m);                                         // the formatted text may reuse the pipeline's space:
         c->d_bwt = c->d_qual = nullptr; c->d_lcp = nullptr; c->d_gcnt = nullptr;   // the eBWT is gone (bfq_fetch_ebwt refuses)
@@ -819,6 +848,21 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
             const size_t mz = c->mark();
             const u64 bound = bfq_codec_bound(sl) < J->cap_stream ? bfq_codec_bound(sl) : J->cap_stream;
             u8 *d_z = c->alloc<u8>(bound + 16);
+            if (ebwtDomain) {   // "BFQEBWT1" | rows | reads | terminator byte | 0 | bytes of the symbols' container | that container | the patches' container
+                if (bound < 40) throw BfqError{BFQ_E_ARG, "stream buffer too small"};
+                const u64 symLen = bfq_codec_compress_device(c, ob, sl, d_z + 40, bound - 40);
+                const u64 patLen = bfq_codec_compress_device(c, op, sl, d_z + 40 + symLen, bound - 40 - symLen);
+                u8 h[40];
+                memcpy(h, "BFQEBWT1", 8);
+                const u64 rows = sl, reads = fq.N;
+                memcpy(h + 8, &rows, 8); memcpy(h + 16, &reads, 8);
+                const u32 tb = (u32)(c->P.term & 0xFF), zero = 0;
+                memcpy(h + 24, &tb, 4); memcpy(h + 28, &zero, 4); memcpy(h + 32, &symLen, 8);
+                HIP_CHECK(hipMemcpyAsync(d_z, h, 40, hipMemcpyHostToDevice, c->stream));
+                c->sync();
+                J->dna_bytes = 40 + symLen + patLen;
+                bfq_download(c, J->out_dna, d_z, J->dna_bytes);
+            } else
             if (J->out_dna) { J->dna_bytes = bfq_codec_compress_device(c, ob, sl, d_z, bound); bfq_download(c, J->out_dna, d_z, J->dna_bytes); }
             if (J->out_qs) { J->qs_bytes = bfq_codec_compress_device(c, oq, sl, d_z, bound); bfq_download(c, J->out_qs, d_z, J->qs_bytes); }
             c->release(mz);
@@ -1035,5 +1079,84 @@ extern "C" int bfq_stream_compress_device(bfq_ctx *c, const uint8_t *d_in, uint6
         *out_len = bfq_codec_compress_device(c, d_in, len, d_out, cap);
         c->sync();
         c->profCollect();
+    });
+}
+
+// orig[r] = patch[r] ? patch[r] : sym[r] (in place in `orig`, which arrives holding the patches)
+__global__ __launch_bounds__(256) void k_ebwt_unpatch(const u8 *__restrict__ sym, u8 *__restrict__ orig, u64 n)
+{
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x)
+        if (!orig[r]) orig[r] = sym[r];
+}
+// rows whose symbol was replaced: flag + replacement in the LF entry, as k_cluster leaves them
+__global__ __launch_bounds__(256) void k_ebwt_mark(const u8 *__restrict__ sym, const u8 *__restrict__ orig, u64 n, u64 *__restrict__ lfq)
+{
+    for (u64 r = (u64)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += (u64)gridDim.x * blockDim.x)
+        if (sym[r] != orig[r]) lfq_set_repl(lfq, r, bfq_base_code(orig[r]), bfq_base_code(sym[r]));
+}
+// eBWT-domain containers (bfq_fastq_job.compress_streams = 2) back to the line streams OUT.fq.dna / OUT.fq.qs: the two
+// containers are decoded on the device, the LF table is built from the rows and the reads are walked out (steps 4 of the
+// path; no clusters: the rows already hold the smoothed result).
+extern "C" int bfq_stream_ebwt_decode(bfq_ctx *c, const uint8_t *h_bwtz, uint64_t len_b, const uint8_t *h_qsz, uint64_t len_q,
+                                      uint8_t *h_dna, uint8_t *h_qs, uint64_t cap, uint64_t *stream_len, uint64_t *n_reads)
+{
+    return guarded(c, [&] {
+        if (!h_bwtz || !h_qsz || len_b < 40 || memcmp(h_bwtz, "BFQEBWT1", 8)) throw BfqError{BFQ_E_ARG, "not a BFQEBWT1 stream"};
+        u64 n = 0, N = 0, symLen = 0;
+        u32 tb = 0;
+        memcpy(&n, h_bwtz + 8, 8); memcpy(&N, h_bwtz + 16, 8); memcpy(&tb, h_bwtz + 24, 4); memcpy(&symLen, h_bwtz + 32, 8);
+        const BfqError bad{BFQ_E_ARG, "damaged BFQEBWT1 stream"};
+        if (symLen > len_b - 40 || N > n) throw bad;
+        const u8 *h_sym = h_bwtz + 40, *h_pat = h_bwtz + 40 + symLen;
+        const u64 patLen = len_b - 40 - symLen;
+        if (bfq_codec_raw_len(h_sym, symLen) != n || bfq_codec_raw_len(h_pat, patLen) != n || bfq_codec_raw_len(h_qsz, len_q) != n) throw bad;
+        if (n > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the streams"};
+        if (stream_len) *stream_len = n;
+        if (n_reads) *n_reads = N;
+        if (!n) return;
+        c->reserve(ws_need_given(n, N, 5 * n + len_b + len_q + bfq_codec_workspace(n) / 2 + (64u << 20)));
+        c->zeroCounters();
+        c->n = n; c->N = N;
+        c->d_bwt = c->alloc<u8>(n + 64); c->d_qual = c->alloc<u8>(n + 64);
+        u8 *d_sym = c->alloc<u8>(n + 64);                          // the symbols the reads get; d_bwt = the eBWT the walk navigates by
+        {
+            const size_t mk = c->mark();
+            u8 *d_z = c->alloc<u8>((len_b > len_q ? len_b : len_q) + 64);
+            bfq_upload(c, d_z, h_sym, symLen);
+            bfq_codec_decompress_device(c, h_sym, d_z, symLen, d_sym, n);
+            bfq_upload(c, d_z, h_pat, patLen);
+            bfq_codec_decompress_device(c, h_pat, d_z, patLen, c->d_bwt, n);
+            KLAUNCH(c, K_MISC, 3.0 * (double)n, k_ebwt_unpatch, bfq_grid(n, 256 * 16), 256, (const u8 *)d_sym, c->d_bwt, n);
+            bfq_upload(c, d_z, h_qsz, len_q);
+            bfq_codec_decompress_device(c, h_qsz, d_z, len_q, c->d_qual, n);
+            c->release(mk);
+        }
+        u64 *d_roff = c->alloc<u64>(N + 2);
+        u32 *lens = c->alloc<u32>(N + 2);
+        u8 *d_dna = c->alloc<u8>(n + 64), *d_q = c->alloc<u8>(n + 64);
+        const bfq_params keep = c->P;
+        c->P.term = (int)tb; c->P.B = 0;                           // the rows are binned already
+        try {
+            RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term, nullptr);
+            KLAUNCH(c, K_MISC, 2.0 * (double)n, k_ebwt_mark, bfq_grid(n, 256 * 16), 256, (const u8 *)d_sym, (const u8 *)c->d_bwt, n, R.lfq);
+            c->fetchCounters();
+            if (c->h_cnt.tot[0] != N) throw BfqError{BFQ_E_NOT_EBWT, "terminator rows do not match the header"};
+            bool guessed = false;
+            if (N && (n - N) % N == 0) { bfq_fixed_offsets(c, N, (n - N) / N, d_roff); guessed = true; }
+            else count_lengths(c, R, d_roff, lens);
+            StreamOut so{h_dna, h_qs};
+            invert_lines(c, R, d_roff, d_dna, d_q, &so);
+            c->fetchCounters();
+            if (guessed && c->h_cnt.errInvert) {                   // not all of one length after all
+                HIP_CHECK(hipMemsetAsync(&c->d_cnt->errInvert, 0, sizeof(u64), c->stream));
+                count_lengths(c, R, d_roff, lens);
+                invert_lines(c, R, d_roff, d_dna, d_q, &so);
+                c->fetchCounters();
+            }
+            c->P = keep;
+        } catch (...) { c->P = keep; throw; }
+        c->profCollect();
+        check_counters(c);
+        c->d_bwt = c->d_qual = nullptr;
     });
 }

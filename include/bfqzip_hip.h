@@ -165,7 +165,8 @@ typedef struct bfq_fastq_job {
     /* steps 1-5 in one call: the streams leave as BFQRANS1 containers (bfq_stream_compress, below) instead of raw bytes --
      * what `BFQzip.py --m2/--m3` without -0 produces through 7z / bsc (BFQzip.py:253-275).  The raw streams never cross
      * the bus.  stream_len / hdr_len stay the RAW lengths; *_bytes = what was written to out_dna / out_qs / out_hdr. */
-    int32_t  compress_streams; int32_t reserved0;
+    int32_t  compress_streams;                /* 1: as described; 2: eBWT-domain containers (bfq_stream_ebwt_decode, below) */
+    int32_t  reserved0;
     uint64_t dna_bytes, qs_bytes, hdr_bytes;
 } bfq_fastq_job;
 int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *job, bfq_stats *st);
@@ -242,6 +243,13 @@ uint64_t bfq_stream_bound(uint64_t len);                          /* capacity th
 int64_t  bfq_stream_raw_len(const uint8_t *h_in, uint64_t len);   /* raw length of a container, -1 if it is not one  */
 int bfq_stream_compress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len);
 int bfq_stream_decompress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len);
+/* eBWT-domain containers (bfq_fastq_job.compress_streams = 2; out_fastq must be NULL): out_dna receives "BFQEBWT1" |
+ * u64 rows | u64 reads | u32 terminator byte | u32 0 | the container of the eBWT's symbols AFTER noise reduction, out_qs the
+ * container of the rows' qualities after smoothing (row order, n = bases + reads bytes each).  In row order the symbols of a
+ * deep collection are runs -- half the size of the read-order stream -- and the compressing side skips the inversion.
+ * bfq_stream_ebwt_decode inverts them back to the line streams OUT.fq.dna / OUT.fq.qs (cap >= rows bytes each). */
+int bfq_stream_ebwt_decode(bfq_ctx *c, const uint8_t *h_bwtz, uint64_t len_b, const uint8_t *h_qsz, uint64_t len_q,
+                           uint8_t *h_dna, uint8_t *h_qs, uint64_t cap, uint64_t *stream_len, uint64_t *n_reads);
 /* device-resident form (input and output in device memory): bfq_stream_reserve(len) sizes the workspace once */
 int bfq_stream_reserve(bfq_ctx *c, uint64_t len);
 int bfq_stream_compress_device(bfq_ctx *c, const uint8_t *d_in, uint64_t len, uint8_t *d_out, uint64_t cap, uint64_t *out_len);

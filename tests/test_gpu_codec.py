@@ -66,6 +66,34 @@ def test_job_with_compressed_streams(engine):
     assert np.array_equal(np.asarray(engine.stream_decompress(np.asarray(z2.qs))), np.asarray(plain.qs))
 
 
+def test_ebwt_domain_containers(engine):
+    """compress=2: the rows of the edited eBWT instead of the reads.  The containers decode (CPU statement) to an eBWT whose
+    inversion by the CPU oracle gives the reads of the plain job; the GPU decoder gives the plain job's line streams."""
+    for N, L, Lmax, M, B in ((30000, 100, None, 2, 1), (20000, 40, 90, 1, 0), (5000, 1, 3, 3, 0)):
+        sp = api.synth_spec(N, L, Lmax=Lmax, seed=5 + N)
+        text = np.empty(N * 300, np.uint8)
+        n = engine.synth_fastq(sp, text)
+        engine.set_params(m=5, M=M, B=B)
+        plain = engine.fastq_job([text[:n]], fastq=False, streams=True)
+        z = engine.fastq_job([text[:n]], fastq=False, streams=True, compress=2)
+        assert z.stats == plain.stats
+        bz, qz = np.asarray(z.dna), np.asarray(z.qs)
+        assert bz[:8].tobytes() == b"BFQEBWT1" and len(bz) + len(qz) < len(plain.dna)
+        dna, qs, nr = engine.ebwt_decode(bz, qz)
+        assert nr == N and np.array_equal(dna, np.asarray(plain.dna)) and np.array_equal(qs, np.asarray(plain.qs))
+        # independent of the GPU decoder: the CPU codec decodes the three containers; the rows the walk navigates by
+        # (symbols with the replaced ones patched back) invert, on the CPU oracle, to the INPUT reads' bases
+        sym_len = int(np.frombuffer(bz[32:40].tobytes(), np.uint64)[0])
+        rows_s, rows_p, rows_q = orc.codec_decode(bz[40:40 + sym_len]), orc.codec_decode(bz[40 + sym_len:]), orc.codec_decode(qz)
+        assert int((rows_p != 0).sum()) == plain.stats["modified"]
+        orig = np.where(rows_p != 0, rows_p, rows_s)
+        p = orc.params(K=60000, m=5, M=2, B=0)
+        ob, oq, roff, _ = orc.smooth_invert(orig, rows_q, np.zeros(len(orig), np.uint32), p)   # LCP 0: no clusters
+        hb, hq, hr = api.synth_host(sp)
+        assert np.array_equal(ob, hb) and np.array_equal(roff, hr)
+    engine.set_params(m=5, M=2, B=0)
+
+
 def test_large_stream_round_trip(engine):
     """More segments than one launch has lanes, a model table near its largest size (6 symbols, order 6)."""
     rng = np.random.default_rng(5)
