@@ -157,6 +157,9 @@ def stream_codec(api, eng, outs, lens, N, L, log, with_cpu, text=None):
         log(f"stream_codec {k}: {len(raw)} -> {len(blob)} bytes, {dt * 1e3:.0f} ms")
         if with_cpu:
             n = min(len(raw), 32 << 20)
+            nlp = np.flatnonzero(raw[max(0, n - 65536):n] == 10)       # whole lines (the line-delta transform wants them)
+            if len(nlp):
+                n = max(0, n - 65536) + int(nlp[-1]) + 1
             with tempfile.NamedTemporaryFile(dir="/dev/shm", delete=False) as f:
                 f.write(raw[:n].tobytes())
             try:
