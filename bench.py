@@ -207,6 +207,20 @@ def stream_codec(api, eng, outs, lens, N, L, log, with_cpu, text=None):
                                       "eBWT (symbols + the replaced rows' originals, qualities) through the codec, no inversion; "
                                       "bfq_stream_ebwt_decode: containers -> LF table -> reads (OUT.fq.dna / OUT.fq.qs)"}
         log(f"ebwt domain: {dt * 1e3:.0f} ms, {nb} bytes, decode {dt2 * 1e3:.0f} ms, equal {same2}")
+        eng.fastq_job([text], streams=True, hdr=True, fastq=False, out=zb, compress=3)
+        t0 = time.perf_counter()
+        z3 = eng.fastq_job([text], streams=True, hdr=True, fastq=False, out=zb, compress=3)
+        dt3 = time.perf_counter() - t0
+        nb3 = int(len(z3.dna) + len(z3.qs) + len(z3.hdr))
+        t0 = time.perf_counter()
+        d3, q3, nr3 = eng.ebwt_decode(z3.dna, z3.qs, out=(back[0].array, back[1].array))
+        dt4 = time.perf_counter() - t0
+        same3 = bool(nr3 == N and np.array_equal(d3, outs["dna"].array[:lens["dna"]]) and np.array_equal(q3, outs["qs"].array[:lens["qs"]]))
+        res["ebwt_domain_qs_by_read"] = {"wall_ms": round(dt3 * 1e3, 1), "Mbases_per_s": round(N * L / 1e6 / dt3, 1), "bytes_out": nb3,
+                                         "ratio_to_raw_streams": round(tot_raw / max(nb3, 1), 2), "decode_wall_ms": round(dt4 * 1e3, 1),
+                                         "decoded_streams_equal_e2e_host": same3,
+                                         "what": "compress_streams = 3: bases as rows of the edited eBWT, qualities as the read-order stream (one walk while compressing)"}
+        log(f"ebwt domain, qualities by read: {dt3 * 1e3:.0f} ms, {nb3} bytes, decode {dt4 * 1e3:.0f} ms, equal {same3}")
         for b in back:
             b.free()
         for v in zo.values():

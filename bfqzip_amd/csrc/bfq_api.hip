@@ -381,7 +381,7 @@ static void invert_lines(bfq_ctx *c, const RankIndex &R, const u64 *d_roff, u8 *
 // noise reduction, quality after smoothing (binned when B = 1; a constant at the terminator rows, whose quality byte never
 // reaches a FASTQ) -- instead of the reads they invert to.  In row order the symbols of a deep collection are runs: they
 // code to half the size of the read-order stream, and the compressing side skips the inversion altogether.
-struct EbwtOut { u8 *sym, *qual, *patch; };
+struct EbwtOut { u8 *sym, *qual, *patch; u8 *lineDna, *lineQs; };   // lineQs != nullptr: the qualities in READ order as well (a walk)
 // patch[r] = the ORIGINAL symbol of a row whose base was replaced, else 0: the walk navigates by the original eBWT
 // (invert, bfq_int.cpp:782-790: base = replaced ? BWT_MOD : bwt[j], j = LF(j) of the unchanged BWT).
 __global__ __launch_bounds__(256) void k_ebwt_rows(const u64 *__restrict__ lfq, u64 n, u32 term, int B, u8 *__restrict__ sym, u8 *__restrict__ qual,
@@ -414,6 +414,7 @@ static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_
     bfq_clusters(c, R, c->d_bwt, c->d_qual, in, n);
     if (eo) {
         KLAUNCH(c, K_MISC, 10.0 * (double)n, k_ebwt_rows, bfq_grid(n, 256), 256, (const u64 *)R.lfq, n, (u32)(c->P.term & 0xFF), c->P.B, eo->sym, eo->qual, eo->patch);
+        if (eo->lineQs) { StreamOut none{nullptr, nullptr}; invert_lines(c, R, d_roff, eo->lineDna, eo->lineQs, &none); }
         return;
     }
     if (so) { invert_lines(c, R, d_roff, d_out_bases, d_out_quals, so); return; }
@@ -801,13 +802,15 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         bfq_fastq_parse(c, d_fq, len, &fq);
         J->n_reads = fq.N; J->total_bases = fq.total;
         const bool wantStreams = J->out_dna || J->out_qs || J->out_hdr;
-        const bool ebwtDomain = J->compress_streams == 2;          // rows of the edited eBWT instead of reads: no inversion on this side
+        const bool ebwtDomain = J->compress_streams == 2 || J->compress_streams == 3;   // rows of the edited eBWT instead of reads
+        const bool qsByRead = J->compress_streams == 3;            // ... but the qualities in read order (they keep their along-the-read correlation)
         if (ebwtDomain && (!J->out_dna || !J->out_qs || J->out_fastq)) throw BfqError{BFQ_E_ARG, "compress_streams = 2 gives out_dna and out_qs (no FASTQ text)"};
         const bool lines = J->out_dna || J->out_qs;               // the inversion writes the line streams itself
         const u64 sl = fq.total + fq.N;
         if (lines && sl > J->cap_stream) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
         u8 *ob = c->alloc<u8>((lines ? sl : fq.total) + 64), *oq = c->alloc<u8>((lines ? sl : fq.total) + 64);
         u8 *op = ebwtDomain ? c->alloc<u8>(sl + 64) : nullptr;    // eBWT domain: the replaced rows' original symbols
+        u8 *lineDna = qsByRead ? c->alloc<u8>(sl + 64) : nullptr, *lineQs = qsByRead ? c->alloc<u8>(sl + 64) : nullptr;
         // per part: index of its first record, and where its share of every output starts (np + 1 entries each)
         u64 *d_pidx = c->alloc<u64>(np + 1), *d_pick = c->alloc<u64>(4 * (np + 1));
         bfq_fastq_part_index(c, &fq, ps.data(), np, d_pidx);
@@ -839,7 +842,7 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         size_t m = c->mark();
         bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
         StreamOut so{cz ? nullptr : J->out_dna, cz ? nullptr : J->out_qs};
-        EbwtOut eo{ob, oq, op};                                       // (n = total + N rows: the line-stream buffers have exactly that size)
+        EbwtOut eo{ob, oq, op, lineDna, lineQs};                                       // (n = total + N rows: the line-stream buffers have exactly that size)
         steps234_device(c, fq.roff, ob, oq, nullptr, lines ? &so : nullptr, ebwtDomain ? &eo : nullptr);
         if (lines) { J->stream_len = sl; if (!cz) { J->dna_bytes = J->out_dna ? sl : 0; J->qs_bytes = J->out_qs ? sl : 0; } }
         c->release(m);                                         // the formatted text may reuse the pipeline's space:
@@ -856,15 +859,15 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
                 memcpy(h, "BFQEBWT1", 8);
                 const u64 rows = sl, reads = fq.N;
                 memcpy(h + 8, &rows, 8); memcpy(h + 16, &reads, 8);
-                const u32 tb = (u32)(c->P.term & 0xFF), zero = 0;
-                memcpy(h + 24, &tb, 4); memcpy(h + 28, &zero, 4); memcpy(h + 32, &symLen, 8);
+                const u32 tb = (u32)(c->P.term & 0xFF), flags = qsByRead ? 1u : 0u;   // flags bit 0: the quality container is in read order
+                memcpy(h + 24, &tb, 4); memcpy(h + 28, &flags, 4); memcpy(h + 32, &symLen, 8);
                 HIP_CHECK(hipMemcpyAsync(d_z, h, 40, hipMemcpyHostToDevice, c->stream));
                 c->sync();
                 J->dna_bytes = 40 + symLen + patLen;
                 bfq_download(c, J->out_dna, d_z, J->dna_bytes);
             } else
             if (J->out_dna) { J->dna_bytes = bfq_codec_compress_device(c, ob, sl, d_z, bound); bfq_download(c, J->out_dna, d_z, J->dna_bytes); }
-            if (J->out_qs) { J->qs_bytes = bfq_codec_compress_device(c, oq, sl, d_z, bound); bfq_download(c, J->out_qs, d_z, J->qs_bytes); }
+            if (J->out_qs) { J->qs_bytes = bfq_codec_compress_device(c, qsByRead ? lineQs : oq, sl, d_z, bound); bfq_download(c, J->out_qs, d_z, J->qs_bytes); }
             c->release(mz);
         }
         if (J->out_fastq) {
@@ -1103,8 +1106,9 @@ extern "C" int bfq_stream_ebwt_decode(bfq_ctx *c, const uint8_t *h_bwtz, uint64_
     return guarded(c, [&] {
         if (!h_bwtz || !h_qsz || len_b < 40 || memcmp(h_bwtz, "BFQEBWT1", 8)) throw BfqError{BFQ_E_ARG, "not a BFQEBWT1 stream"};
         u64 n = 0, N = 0, symLen = 0;
-        u32 tb = 0;
-        memcpy(&n, h_bwtz + 8, 8); memcpy(&N, h_bwtz + 16, 8); memcpy(&tb, h_bwtz + 24, 4); memcpy(&symLen, h_bwtz + 32, 8);
+        u32 tb = 0, flags = 0;
+        memcpy(&n, h_bwtz + 8, 8); memcpy(&N, h_bwtz + 16, 8); memcpy(&tb, h_bwtz + 24, 4); memcpy(&flags, h_bwtz + 28, 4); memcpy(&symLen, h_bwtz + 32, 8);
+        const bool qsByRead = flags & 1u;
         const BfqError bad{BFQ_E_ARG, "damaged BFQEBWT1 stream"};
         if (symLen > len_b - 40 || N > n) throw bad;
         const u8 *h_sym = h_bwtz + 40, *h_pat = h_bwtz + 40 + symLen;
@@ -1129,6 +1133,10 @@ extern "C" int bfq_stream_ebwt_decode(bfq_ctx *c, const uint8_t *h_bwtz, uint64_
             KLAUNCH(c, K_MISC, 3.0 * (double)n, k_ebwt_unpatch, bfq_grid(n, 256 * 16), 256, (const u8 *)d_sym, c->d_bwt, n);
             bfq_upload(c, d_z, h_qsz, len_q);
             bfq_codec_decompress_device(c, h_qsz, d_z, len_q, c->d_qual, n);
+            if (qsByRead) {                                        // already the line stream OUT.fq.qs: out as it is; the walk carries dummies
+                if (h_qs) bfq_download(c, h_qs, c->d_qual, n);
+                HIP_CHECK(hipMemsetAsync(c->d_qual, '!', n, c->stream));
+            }
             c->release(mk);
         }
         u64 *d_roff = c->alloc<u64>(N + 2);
@@ -1144,7 +1152,7 @@ extern "C" int bfq_stream_ebwt_decode(bfq_ctx *c, const uint8_t *h_bwtz, uint64_
             bool guessed = false;
             if (N && (n - N) % N == 0) { bfq_fixed_offsets(c, N, (n - N) / N, d_roff); guessed = true; }
             else count_lengths(c, R, d_roff, lens);
-            StreamOut so{h_dna, h_qs};
+            StreamOut so{h_dna, qsByRead ? nullptr : h_qs};
             invert_lines(c, R, d_roff, d_dna, d_q, &so);
             c->fetchCounters();
             if (guessed && c->h_cnt.errInvert) {                   // not all of one length after all

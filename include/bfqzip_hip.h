@@ -165,7 +165,8 @@ typedef struct bfq_fastq_job {
     /* steps 1-5 in one call: the streams leave as BFQRANS1 containers (bfq_stream_compress, below) instead of raw bytes --
      * what `BFQzip.py --m2/--m3` without -0 produces through 7z / bsc (BFQzip.py:253-275).  The raw streams never cross
      * the bus.  stream_len / hdr_len stay the RAW lengths; *_bytes = what was written to out_dna / out_qs / out_hdr. */
-    int32_t  compress_streams;                /* 1: as described; 2: eBWT-domain containers (bfq_stream_ebwt_decode, below) */
+    int32_t  compress_streams;                /* 1: as described; 2: eBWT-domain containers (bfq_stream_ebwt_decode, below);
+                                                 3: the same with the qualities in read order (smallest output) */
     int32_t  reserved0;
     uint64_t dna_bytes, qs_bytes, hdr_bytes;
 } bfq_fastq_job;
@@ -244,9 +245,12 @@ int64_t  bfq_stream_raw_len(const uint8_t *h_in, uint64_t len);   /* raw length 
 int bfq_stream_compress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len);
 int bfq_stream_decompress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len);
 /* eBWT-domain containers (bfq_fastq_job.compress_streams = 2; out_fastq must be NULL): out_dna receives "BFQEBWT1" |
- * u64 rows | u64 reads | u32 terminator byte | u32 0 | the container of the eBWT's symbols AFTER noise reduction, out_qs the
+ * u64 rows | u64 reads | u32 terminator byte | u32 flags | u64 bytes of the next container | the container of the eBWT's
+ * symbols AFTER noise reduction | the container of the replaced rows' original symbols (0 elsewhere), out_qs the
  * container of the rows' qualities after smoothing (row order, n = bases + reads bytes each).  In row order the symbols of a
  * deep collection are runs -- half the size of the read-order stream -- and the compressing side skips the inversion.
+ * compress_streams = 3 (flags bit 0) keeps the qualities in READ order (OUT.fq.qs as in mode 1: they code better along the
+ * read) at the price of one walk on the compressing side.
  * bfq_stream_ebwt_decode inverts them back to the line streams OUT.fq.dna / OUT.fq.qs (cap >= rows bytes each). */
 int bfq_stream_ebwt_decode(bfq_ctx *c, const uint8_t *h_bwtz, uint64_t len_b, const uint8_t *h_qsz, uint64_t len_q,
                            uint8_t *h_dna, uint8_t *h_qs, uint64_t cap, uint64_t *stream_len, uint64_t *n_reads);

@@ -91,6 +91,13 @@ def test_ebwt_domain_containers(engine):
         ob, oq, roff, _ = orc.smooth_invert(orig, rows_q, np.zeros(len(orig), np.uint32), p)   # LCP 0: no clusters
         hb, hq, hr = api.synth_host(sp)
         assert np.array_equal(ob, hb) and np.array_equal(roff, hr)
+        # mode 3: the same rows for the bases, the qualities as the read-order stream of mode 1
+        z3 = engine.fastq_job([text[:n]], fastq=False, streams=True, compress=3)
+        z1 = engine.fastq_job([text[:n]], fastq=False, streams=True, compress=1)
+        b3, q3 = np.asarray(z3.dna), np.asarray(z3.qs)
+        assert np.array_equal(q3, np.asarray(z1.qs)) and np.array_equal(b3[40:], bz[40:]) and b3[28] == 1
+        dna3, qs3, nr3 = engine.ebwt_decode(b3, q3)
+        assert nr3 == N and np.array_equal(dna3, np.asarray(plain.dna)) and np.array_equal(qs3, np.asarray(plain.qs))
     engine.set_params(m=5, M=2, B=0)
 
 
