@@ -233,8 +233,9 @@ class Engine:
         J.parts = tp; J.nparts = np_; J.keep_headers = 1 if keep_headers else 0
         J.compress_streams = int(compress)                     # 0 raw, 1 containers of the streams, 2 eBWT-domain containers
         bf = buf("fastq", fastq, inlen + 5 * np_ + 16)
-        bd, bq = buf("dna", streams, inlen + 16), buf("qs", streams, inlen + 16)
-        bh = buf("hdr", hdr, inlen + 16)
+        zcap = (2 * int(self.L.bfq_stream_bound(inlen)) + 64) if compress else 0      # a tiny stream's container is larger than the stream
+        bd, bq = buf("dna", streams, max(inlen + 16, zcap)), buf("qs", streams, max(inlen + 16, zcap))
+        bh = buf("hdr", hdr, max(inlen + 16, zcap))
         if bf is not None:
             J.out_fastq = bf.ctypes.data; J.cap_fastq = len(bf)
         if bd is not None:

@@ -164,7 +164,9 @@ typedef struct bfq_fastq_job {
              part_stream_off[BFQ_MAX_PARTS + 1], part_hdr_off[BFQ_MAX_PARTS + 1];
     /* steps 1-5 in one call: the streams leave as BFQRANS1 containers (bfq_stream_compress, below) instead of raw bytes --
      * what `BFQzip.py --m2/--m3` without -0 produces through 7z / bsc (BFQzip.py:253-275).  The raw streams never cross
-     * the bus.  stream_len / hdr_len stay the RAW lengths; *_bytes = what was written to out_dna / out_qs / out_hdr. */
+     * the bus.  stream_len / hdr_len stay the RAW lengths; *_bytes = what was written to out_dna / out_qs / out_hdr.
+     * Capacities: bfq_stream_bound(raw length) always suffices (a tiny stream's container is larger than the stream; the raw
+     * length is enough from a few MB on); out_dna of modes 2 / 3 holds two containers: twice that + 40. */
     int32_t  compress_streams;                /* 1: as described; 2: eBWT-domain containers (bfq_stream_ebwt_decode, below);
                                                  3: the same with the qualities in read order (smallest output) */
     int32_t  reserved0;

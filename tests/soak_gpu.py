@@ -9,7 +9,9 @@ Round 2 adds per case: step 1 in one piece or pile by pile (drawn at random; BFQ
 every pile again), bfq_int mode = LCP deduced from the BWT alone (k_bfs.hip), on small cases also with the ties of
 identical suffixes shuffled, the FASTQ job (text in, FASTQ text + streams out) against the oracle's reads, and the global mode
 (parallel.run_global on one rank: two-symbol piles, position-mode clusters) against the same.
-Round 2 totals: 25 623 cases / 6.8 G rows in twelve runs (the last seven with the 40-bit sort key), all bit-exact."""
+Since the stream codec exists every case also checks step 5 (containers = CPU statement, eBWT-domain containers back to the streams).
+Round 2 totals: 27 506 cases / 7.3 G rows in thirteen runs (the last eight with the 40-bit sort key, the last one with the
+step-5 checks), all bit-exact."""
 import sys, time, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -95,6 +97,16 @@ def run_case(eng, O, seed):
         res = eng.fastq_job([text], fastq=True, streams=True)
         ok = ok and res.fastq.tobytes() == fastq.format_fastq(ob, oq, r) and res.dna.tobytes() == fastq.format_lines(ob, r) \
             and res.qs.tobytes() == fastq.format_lines(oq, r)
+        # step 5: the streams through the codec (= the CPU statement, byte for byte), and the eBWT-domain containers
+        # (rows of the edited eBWT; qualities by row or by read) back to the same streams
+        for mode in (1, 2, 3):
+            z = eng.fastq_job([text], fastq=False, streams=True, compress=mode)
+            if mode == 1:
+                ok = ok and np.array_equal(np.asarray(z.dna), O.codec_encode(np.asarray(res.dna))) \
+                    and np.array_equal(np.asarray(eng.stream_decompress(np.asarray(z.qs))), np.asarray(res.qs))
+            else:
+                d2, q2, nr = eng.ebwt_decode(np.asarray(z.dna), np.asarray(z.qs))
+                ok = ok and nr == len(r) - 1 and np.array_equal(d2, np.asarray(res.dna)) and np.array_equal(q2, np.asarray(res.qs))
         if par["k"] >= 2 and len(r) > 1:                         # global mode (one eBWT dealt pile by pile, position-mode clusters) = the same reads
             import tempfile
             from bfqzip_amd import parallel
