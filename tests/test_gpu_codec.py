@@ -206,3 +206,16 @@ def test_bsc_front_end(tmp_path):
     assert (tmp_path / "back").read_bytes() == raw
     r = subprocess.run([exe, "d", str(f), str(tmp_path / "x")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode != 0
+    # eBWT-domain containers back to the line streams (`bsc x`)
+    eng = api.Engine(m=5)
+    sp = api.synth_spec(3000, 60, seed=3)
+    text = np.empty(3000 * 200, np.uint8)
+    n = eng.synth_fastq(sp, text)
+    plain = eng.fastq_job([text[:n]], fastq=False, streams=True)
+    z = eng.fastq_job([text[:n]], fastq=False, streams=True, compress=3)
+    (tmp_path / "rows.z").write_bytes(np.asarray(z.dna).tobytes()); (tmp_path / "qs.z").write_bytes(np.asarray(z.qs).tobytes())
+    eng.close()
+    r = subprocess.run([exe, "x", str(tmp_path / "rows.z"), str(tmp_path / "qs.z"), str(tmp_path / "o.dna"), str(tmp_path / "o.qs")],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert (tmp_path / "o.dna").read_bytes() == np.asarray(plain.dna).tobytes() and (tmp_path / "o.qs").read_bytes() == np.asarray(plain.qs).tobytes()
