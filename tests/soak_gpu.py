@@ -10,8 +10,8 @@ every pile again), bfq_int mode = LCP deduced from the BWT alone (k_bfs.hip), on
 identical suffixes shuffled, the FASTQ job (text in, FASTQ text + streams out) against the oracle's reads, and the global mode
 (parallel.run_global on one rank: two-symbol piles, position-mode clusters) against the same.
 Since the stream codec exists every case also checks step 5 (containers = CPU statement, eBWT-domain containers back to the streams).
-Round 2 totals: 27 506 cases / 7.3 G rows in thirteen runs (the last eight with the 40-bit sort key, the last one with the
-step-5 checks), all bit-exact."""
+Round 2 totals: 31 992 cases / 8.4 G rows in fifteen runs (the last ten with the 40-bit sort key, the last three with the
+step-5 checks, one of those pile by pile), all bit-exact."""
 import sys, time, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
