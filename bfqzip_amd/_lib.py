@@ -13,7 +13,8 @@ _LIB = None
 
 SYMBOLS = [
     "bfq_default_params", "bfq_create", "bfq_create_error", "bfq_destroy", "bfq_set_params",
-    "bfq_last_error", "bfq_stream", "bfq_device_count", "bfq_build_ebwt", "bfq_count_reads",
+    "bfq_last_error", "bfq_stream", "bfq_device_count", "bfq_pick_device", "bfq_device_lease", "bfq_device_release",
+    "bfq_phase_enable", "bfq_phase", "bfq_phase_report", "bfq_build_ebwt", "bfq_count_reads",
     "bfq_smooth_invert", "bfq_run_reads", "bfq_run_reads_device", "bfq_fetch_ebwt",
     "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_fastq_run_streams",
     "bfq_smooth_invert_fastq", "bfq_fastq_run_job", "bfq_host_alloc", "bfq_host_free",
@@ -104,6 +105,12 @@ def lib():
         L.bfq_workspace_bytes.argtypes = [C.c_void_p]
         L.bfq_synth_total.restype = C.c_uint64
         vp, u64 = C.c_void_p, C.c_uint64
+        L.bfq_pick_device.argtypes = [C.c_char_p, C.c_int]
+        L.bfq_device_lease.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]
+        L.bfq_device_release.argtypes = [C.c_int]
+        L.bfq_phase_enable.argtypes = [C.c_int]
+        L.bfq_phase.argtypes = [C.c_char_p]
+        L.bfq_phase_report.argtypes = [C.c_char_p]
         L.bfq_build_ebwt.argtypes = [vp, vp, vp, vp, u64, C.c_int, vp, vp, vp]
         L.bfq_count_reads.argtypes = [vp, u64, C.c_int, C.POINTER(u64)]
         L.bfq_smooth_invert.argtypes = [vp, vp, vp, vp, C.c_int, u64, vp, vp, vp, C.POINTER(Stats)]

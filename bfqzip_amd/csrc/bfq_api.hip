@@ -11,6 +11,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <unistd.h>
+#include <errno.h>
+#include <algorithm>
 #include <new>
 #include "bfq_internal.h"
 #include "bfq_synth.h"
@@ -34,7 +36,7 @@ void bfq_ctx::reserve(size_t bytes)
         clock_gettime(CLOCK_MONOTONIC, &t0);
         hipError_t e = hipMalloc((void **)&ws, bytes);
         clock_gettime(CLOCK_MONOTONIC, &t1);
-        if (getenv("BFQ_TRACE")) fprintf(stderr, "[bfq] workspace %.1f GiB: hipMalloc %.3f s\n", bytes / 1073741824.0, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
+        if (bfq_env().trace) fprintf(stderr, "[bfq] workspace %.1f GiB: hipMalloc %.3f s\n", bytes / 1073741824.0, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
         if (e != hipSuccess) {
             ws = nullptr;
             char b[160];
@@ -118,6 +120,37 @@ extern "C" int bfq_device_count(void)
     return nd;
 }
 
+// the GPU a one-shot tool runs on (include/bfqzip_hip.h): lease by PCI bus id, so that processes with different
+// HIP_VISIBLE_DEVICES still agree on which lock file stands for which GPU
+extern "C" int bfq_pick_device(char *info, int info_cap)
+{
+    const BfqEnv &E = bfq_env();
+    int real = 0;
+    if (hipGetDeviceCount(&real) != hipSuccess || real < 1) { (void)hipGetLastError(); return BFQ_E_HIP; }
+    const int slots = E.fakeDevices > 0 ? E.fakeDevices : real;
+    if (E.device >= slots) return BFQ_E_ARG;
+    if (!E.lease) {
+        const int d = E.device >= 0 ? E.device % real : 0;
+        if (info && info_cap > 0) snprintf(info, info_cap, "device %d (no lease)", d);
+        return d;
+    }
+    std::vector<std::string> ids(slots);
+    std::vector<const char *> idp(slots);
+    for (int k = 0; k < slots; k++) {
+        char bus[64] = {0};
+        if (E.fakeDevices > 0) ids[k] = "fake" + std::to_string(k) + "of" + std::to_string(slots);
+        else if (hipDeviceGetPCIBusId(bus, sizeof bus, k) == hipSuccess && bus[0]) ids[k] = std::string("gpu-") + bus;
+        else { (void)hipGetLastError(); ids[k] = "gpu-index" + std::to_string(k); }
+        idp[k] = ids[k].c_str();
+    }
+    char path[256] = {0};
+    double waited = 0;
+    const int slot = bfq_device_lease(slots, idp.data(), E.device, path, sizeof path, &waited);
+    if (slot < 0) return slot;
+    if (info && info_cap > 0) snprintf(info, info_cap, "device %d lease %s waited %.3f s", slot % real, path, waited);
+    return slot % real;
+}
+
 extern "C" bfq_ctx *bfq_create(int device, const bfq_params *p)
 {
     bfq_ctx *c = nullptr;
@@ -129,6 +162,7 @@ extern "C" bfq_ctx *bfq_create(int device, const bfq_params *p)
         c = new bfq_ctx();
         c->device = device;
         if (p) c->P = *p; else bfq_default_params(&c->P);
+        c->env = bfq_env_read();
         HIP_CHECK(hipSetDevice(device));
         HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIP_CHECK(hipMalloc((void **)&c->d_cnt, sizeof(DevCounters)));
@@ -185,6 +219,7 @@ extern "C" int bfq_set_params(bfq_ctx *c, const bfq_params *p)
 {
     if (!c || !p) return BFQ_E_ARG;
     c->P = *p;
+    c->env = bfq_env_read();
     return BFQ_OK;
 }
 extern "C" const char *bfq_last_error(bfq_ctx *c) { return c ? c->err.c_str() : "null context"; }
@@ -280,7 +315,7 @@ static size_t ws_need_given(u64 n, u64 N, u64 extra)
 static void reserve_step1(bfq_ctx *c, u64 n, u64 N, u64 extra)
 {
     int mode = c->P.piles;
-    if (const char *e = getenv("BFQ_PILES")) mode = atoi(e) ? 1 : -1;
+    if (c->env.piles) mode = c->env.piles;
     const u64 cap = n / 10 * 3 + (1u << 20);                     // a DNA pile holds about a quarter of the suffixes; larger ones are split again
     c->piles = false;
     if (mode <= 0) {
@@ -299,8 +334,8 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     u64 n = total + N;
     if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^37 rows)"};
     c->n = n; c->N = N;
-    c->d_bwt = c->alloc<u8>(n + 64);
-    c->d_qual = c->alloc<u8>(n + 64);
+    c->d_bwt = c->extBwt ? c->extBwt : c->alloc<u8>(n + 64);
+    c->d_qual = c->extQual ? c->extQual : c->alloc<u8>(n + 64);
     c->d_lcp = c->alloc<u16>(n + 64);
     c->d_gcnt = c->alloc<u32>(6 * (n / 256 + 1));
     c->gcntTerm = termOut & 0xFF;
@@ -325,6 +360,7 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     bfq_emit_bwt(c, A, n, termOut, c->d_bwt, c->d_qual, c->d_gcnt);
     if (c->keepRecs) { c->release(mKeep); c->d_w12 = A.w12; c->d_text3 = text3; c->keepMark = m0; }
     else c->release(m0);
+    if (c->onRows) c->onRows(0, n);
 }
 
 // ---------------------------------------------------------------- steps 2-4
@@ -351,7 +387,7 @@ static void invert_lines(bfq_ctx *c, const RankIndex &R, const u64 *d_roff, u8 *
 {
     const u64 N = c->N;
     const bool pinned = (!so->h_dna || bfq_is_pinned(so->h_dna)) && (!so->h_qs || bfq_is_pinned(so->h_qs));
-    const int C = (pinned && N >= (1u << 16) && !getenv("BFQ_NO_OVERLAP")) ? 8 : 1;
+    const int C = (pinned && N >= (1u << 16) && !c->env.noOverlap) ? 8 : 1;
     if (C == 1) {
         bfq_invert(c, R, N, d_roff, c->P.B, d_dna, d_qs, 0, ~0ull, true);
         const u64 sl = (c->n - N) + N;
@@ -406,7 +442,7 @@ static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_
     RankIndex R = bfq_rank_build(c, c->d_bwt, c->d_qual, n, c->P.term, gc);
     bool guessed = false;
     if (lens) {
-        if (N && (n - N) % N == 0 && !getenv("BFQ_NO_LENGTH_GUESS")) { bfq_fixed_offsets(c, N, (n - N) / N, d_roff); guessed = true; }
+        if (N && (n - N) % N == 0 && !c->env.noLengthGuess) { bfq_fixed_offsets(c, N, (n - N) / N, d_roff); guessed = true; }
         else count_lengths(c, R, d_roff, lens);
     }
     u8 *in = c->alloc<u8>(n + 64);
@@ -478,7 +514,7 @@ extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const ui
         if (st) memset(st, 0, sizeof *st);
         reserve_step1(c, total + N, N, 0);
         c->zeroCounters();
-        const bool posMode = !c->piles && getenv("BFQ_POSMODE") && atoi(getenv("BFQ_POSMODE"));
+        const bool posMode = !c->piles && c->env.posMode;
         c->keepRecs = posMode;
         bfq_step1_device(c, d_bases, d_quals, (const u64 *)d_read_off, N, total, c->P.term, st);
         c->keepRecs = false;
@@ -589,7 +625,9 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
         const bool haveLcp = !h_lcp.null();
         if (haveLcp && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
         const u64 npad = (n + 255) & ~255ull;
+        bfq_phase("alloc");
         u8 *in_bwt = c->textBuf(2 * npad + 256), *in_qs = in_bwt + npad;
+        bfq_phase("read_h2d");
         bfq_upload(c, in_bwt, h_bwt, n);
         c->zeroCounters();
         if (n) KLAUNCH(c, K_MISC, (double)n, k_count_byte, (unsigned)(n / 4096 + 1 < 2048 ? n / 4096 + 1 : 2048), 256, (const u8 *)in_bwt, n, (u32)(c->P.term & 0xFF), &c->d_cnt->pad[0]);
@@ -597,8 +635,16 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
         const u64 N = c->h_cnt.pad[0];
         if (n && N == 0) throw BfqError{BFQ_E_NOT_EBWT, "no terminator in the eBWT"};
         u64 total = n - N;
+        bfq_phase("alloc");
         c->reserve(ws_need_given(n, N, extraWs + (haveLcp ? (size_t)lcp_bytes * n : 0)));
-        bfq_upload(c, in_qs, h_bwtqs, n);
+        bfq_phase("read_h2d");
+        // the qualities are not needed before the LF table is built: a pageable / file source is staged by a helper thread
+        // while this thread goes on (the LCP deduction from the BWT alone takes longer than the upload)
+        BfqAsyncUpload *qsUp = nullptr;
+        const bool qsAsync = !haveLcp && n >= (64u << 20) && !(h_bwtqs.ptr && bfq_is_pinned(h_bwtqs.ptr)) && !c->env.noOverlap;
+        if (qsAsync) qsUp = bfq_upload_begin(c, in_qs, h_bwtqs, n);
+        else bfq_upload(c, in_qs, h_bwtqs, n);
+        struct Join { BfqAsyncUpload *u; ~Join() { if (u) { try { bfq_upload_join(u); } catch (...) {} } } } joinGuard{qsUp};
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
         u64 *d_roff = c->alloc<u64>(N + 1);
         u32 *lens = c->alloc<u32>(N + 1);
@@ -617,9 +663,12 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
             c->release(mr);
         } else {
             // bfq_int deduces the LCP from the BWT alone (detect_minima, bfq_int.cpp:183-300): interval refinement, k_bfs.hip
+            bfq_phase("gpu");
             bfq_lcp_from_bwt(c, in_bwt, n, N, c->P.term & 0xFF, c->d_lcp, c->d_gcnt);
             c->gcntTerm = c->P.term & 0xFF;
         }
+        if (qsUp) { bfq_phase("read_h2d"); joinGuard.u = nullptr; bfq_upload_join(qsUp); }
+        bfq_phase("gpu");
         steps234_device(c, d_roff, ob, oq, lens);
         res->ob = ob; res->oq = oq; res->roff = d_roff; res->N = N; res->total = total;
     }
@@ -673,7 +722,7 @@ static bool src_ends_with_newline(const TextSrc &t)
     if (pread(t.ref.fd, &b, 1, (off_t)(t.ref.off + t.len - 1)) != 1) throw BfqError{BFQ_E_IO, "cannot read the input file"};
     return b == (u8)'\n';
 }
-static u8 *fastq_upload_and_reserve(bfq_ctx *c, const TextSrc *parts, int nparts, std::vector<u64> &pstart)
+static u8 *fastq_upload_and_reserve(bfq_ctx *c, const TextSrc *parts, int nparts, std::vector<u64> &pstart, size_t extraWs = 0)
 {
     pstart.assign(nparts + 1, 0);
     std::vector<u8> addNl(nparts, 0);
@@ -685,16 +734,22 @@ static u8 *fastq_upload_and_reserve(bfq_ctx *c, const TextSrc *parts, int nparts
         if (!src_ends_with_newline(parts[p])) { addNl[p] = 1; len++; }
     }
     pstart[nparts] = len;
+    bfq_phase("alloc");
     u8 *d_fq = c->textBuf(len + 64);
+    bfq_phase("read_h2d");
     for (int p = 0; p < nparts; p++) {
         bfq_upload(c, d_fq + pstart[p], parts[p].ref, parts[p].len);
         if (addNl[p]) HIP_CHECK(hipMemsetAsync(d_fq + pstart[p] + parts[p].len, '\n', 1, c->stream));
     }
+    bfq_phase("alloc");
     c->reserve(16 * (len / 4096 + 16) + (64u << 20));
+    bfq_phase("gpu");
     u64 nlines = bfq_fastq_count_lines(c, d_fq, len);
     u64 N = nlines / 4 + 1;
     u64 nb = len / 2 + 1;                                       // rows <= bytes / 2
-    reserve_step1(c, nb, N, 3 * (len + 4096) + 128 * (N + 64) + 8 * (nlines + 64));
+    bfq_phase("alloc");
+    reserve_step1(c, nb, N, 3 * (len + 4096) + 128 * (N + 64) + 8 * (nlines + 64) + extraWs);
+    bfq_phase("gpu");
     return d_fq;
 }
 
@@ -713,7 +768,7 @@ __global__ __launch_bounds__(256) void k_lcp_narrow(const u16 *__restrict__ lcp,
 }
 
 static void fastq_build_ebwt_core(bfq_ctx *c, TextSrc text, int term_out, HostRef bwt, HostRef qs, HostRef lcp, int lcp_bytes,
-                                  uint64_t cap_rows, uint64_t *n_rows, uint64_t *n_reads, bool earlyFree = false)
+                                  uint64_t cap_rows, uint64_t *n_rows, uint64_t *n_reads)
 {
     if (!lcp.null() && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
     std::vector<u64> ps;
@@ -726,24 +781,6 @@ static void fastq_build_ebwt_core(bfq_ctx *c, TextSrc text, int term_out, HostRe
     if (n_reads) *n_reads = fq.N;
     if (n > cap_rows) throw BfqError{BFQ_E_ARG, "output buffers smaller than the eBWT (need total bases + reads entries)"};
     bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, term_out, nullptr);
-    if (earlyFree && lcp.null() && 2 * (n + 256) <= c->textCap) {
-        // One-shot tools (the _fd entry points): the driver scrubs freed HBM at ~28 GB/s and the NEXT process's first
-        // allocation waits for it (profiles/microbench/alloc_after_exit.hip: 4-6 s behind a process that held 120 GiB).
-        // The eBWT and its qualities move into the text buffer (the text is dead), the workspace is freed now, and the
-        // scrubbing runs while the outputs are still being written.
-        c->fetchCounters();
-        check_counters(c);
-        u8 *keepB = c->d_text, *keepQ = c->d_text + ((n + 255) & ~255ull);
-        HIP_CHECK(hipMemcpyAsync(keepB, c->d_bwt, n, hipMemcpyDeviceToDevice, c->stream));
-        HIP_CHECK(hipMemcpyAsync(keepQ, c->d_qual, n, hipMemcpyDeviceToDevice, c->stream));
-        c->sync();
-        c->profCollect();
-        c->dropWorkspace();
-        if (!bwt.null()) bfq_download(c, bwt, keepB, n);
-        if (!qs.null()) bfq_download(c, qs, keepQ, n);
-        c->sync();
-        return;
-    }
     if (!bwt.null()) bfq_download(c, bwt, c->d_bwt, n);
     if (!qs.null()) bfq_download(c, qs, c->d_qual, n);
     if (!lcp.null()) {
@@ -757,6 +794,118 @@ static void fastq_build_ebwt_core(bfq_ctx *c, TextSrc text, int term_out, HostRe
     c->fetchCounters();
     c->profCollect();
     check_counters(c);
+}
+
+// ---- the one-shot tools (gsufsort / eGap / bfq_int / bfq_ext processes): files in, files out.
+// An output file: mapped and pre-faulted in the background when it is a regular file, written with pwrite otherwise.
+struct OutFile {
+    int fd = -1;
+    bfq_outmap *m = nullptr;
+    HostRef at(u64 off) const { return m ? HostRef::mem(bfq_outmap_ptr(m) + off) : HostRef::file(fd, off); }
+    void open(int f, u64 mapLen, u64 prefault) { fd = f; if (f >= 0) m = bfq_outmap_open(f, mapLen, prefault); }
+    bool close(u64 finalLen)
+    {
+        bool ok = true;
+        if (m) ok = bfq_outmap_close(m, finalLen);
+        else if (fd >= 0) ok = ftruncate(fd, (off_t)finalLen) == 0 || errno == EINVAL;   // EINVAL: not a regular file
+        m = nullptr;
+        return ok;
+    }
+};
+// eBWT rows per byte of a FASTQ file, from the complete records among its first bytes (sizes the background pre-fault of
+// the outputs before the file has been parsed; a wrong guess costs time, never correctness)
+static double sample_rows_per_byte(const TextSrc &t)
+{
+    const size_t want = (size_t)std::min<u64>(t.len, 1u << 20);
+    if (!want) return 0;
+    std::vector<u8> b(want);
+    if (t.ref.ptr) memcpy(b.data(), t.ref.ptr, want);
+    else if (pread(t.ref.fd, b.data(), want, (off_t)t.ref.off) != (ssize_t)want) return 0.45;
+    u64 rows = 0, used = 0;
+    size_t pos = 0;
+    for (;;) {
+        size_t e[4], p = pos;
+        int k = 0;
+        for (; k < 4; k++) {
+            const void *q = p < want ? memchr(b.data() + p, '\n', want - p) : nullptr;
+            if (!q) break;
+            e[k] = (size_t)((const u8 *)q - b.data());
+            p = e[k] + 1;
+        }
+        if (k < 4) break;
+        size_t L = e[1] - (e[0] + 1);
+        if (L && b[e[1] - 1] == '\r') L--;
+        rows += L + 1;
+        used = p;
+        pos = p;
+    }
+    return used ? (double)rows / (double)used : 0.45;
+}
+
+static void fastq_build_ebwt_oneshot(bfq_ctx *c, int fastq_fd, uint64_t len, int term_out, int bwt_fd, int qs_fd, int lcp_fd, int lcp_bytes,
+                                     uint64_t *n_rows, uint64_t *n_reads)
+{
+    const bool wantLcp = lcp_fd >= 0;
+    if (wantLcp && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
+    TextSrc text{HostRef::file(fastq_fd), len};
+    // the outputs are sized to their bound (rows <= bytes / 2) and pre-faulted from the first moment on: by the time the
+    // first pile is sorted the page cache pages exist and the copy out of the staging buffers runs at memcpy speed
+    const u64 capRows = len / 2 + 64, est = (u64)(sample_rows_per_byte(text) * (double)len * 0.98);
+    OutFile ob, oq, ol;
+    ob.open(bwt_fd, capRows, est);
+    oq.open(qs_fd, capRows, est);
+    if (wantLcp) ol.open(lcp_fd, capRows * (u64)lcp_bytes, est * (u64)lcp_bytes);
+    u64 n = 0;
+    bool done = false;
+    auto finish = [&](bool ok) {
+        c->onRows = nullptr; c->extBwt = c->extQual = nullptr;
+        if (!ok) { try { bfq_write_wait(c); } catch (...) {} }
+        const bool a = ob.close(ok ? n : 0), b = oq.close(ok ? n : 0), l = ol.close(ok ? n * (u64)lcp_bytes : 0);
+        if (ok && !(a && b && l)) throw BfqError{BFQ_E_IO, "cannot size the output files"};
+    };
+    try {
+        std::vector<u64> ps;
+        u8 *d_fq = fastq_upload_and_reserve(c, &text, 1, ps, wantLcp ? (size_t)lcp_bytes * (len / 2 + 4096) : 0);
+        c->zeroCounters();
+        DevFastq fq;
+        bfq_fastq_parse(c, d_fq, ps[1], &fq);
+        n = fq.total + fq.N;
+        if (n_rows) *n_rows = n;
+        if (n_reads) *n_reads = fq.N;
+        // The reads are gathered: the FASTQ text is dead and its buffer takes the eBWT and the qualities.  They then outlive
+        // the arena, which is freed as soon as the last pile is emitted: the driver scrubs freed HBM at ~28 GB/s and the NEXT
+        // process's first allocation waits for it (profiles/microbench/alloc_after_exit.hip), so the scrubbing should run
+        // while this process is still writing, not while bfq_int is starting.
+        const u64 npad = (n + 64 + 255) & ~255ull;
+        if (2 * npad <= c->textCap) { c->extBwt = c->d_text; c->extQual = c->d_text + npad; }
+        u8 *raw = (wantLcp && lcp_bytes != 2) ? c->alloc<u8>((size_t)lcp_bytes * n + 64) : nullptr;
+        c->onRows = [&](u64 start, u64 m) {                     // rows [start, start + m) are final: out they go, while the next pile is sorted
+            if (!m) return;
+            if (ob.fd >= 0) bfq_write_async(c, ob.at(start), c->d_bwt + start, m);
+            if (oq.fd >= 0) bfq_write_async(c, oq.at(start), c->d_qual + start, m);
+            if (wantLcp) {
+                if (lcp_bytes == 2) bfq_write_async(c, ol.at(2 * start), c->d_lcp + start, 2 * m);
+                else {
+                    u8 *r = raw + (size_t)lcp_bytes * start;
+                    KLAUNCH(c, K_MISC, (double)(lcp_bytes + 2) * (double)m, k_lcp_narrow, bfq_grid(m, 256), 256, (const u16 *)(c->d_lcp + start), lcp_bytes, m, r);
+                    bfq_write_async(c, ol.at((u64)lcp_bytes * start), r, (size_t)lcp_bytes * m);
+                }
+            }
+        };
+        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, term_out, nullptr);
+        c->onRows = nullptr;
+        c->fetchCounters();                                     // waits for the stream
+        c->profCollect();
+        check_counters(c);
+        bfq_phase("d2h_write");
+        if (c->extBwt && !wantLcp) c->dropWorkspace();
+        bfq_write_wait(c);
+        done = true;
+    } catch (...) {
+        finish(false);
+        throw;
+    }
+    if (done) finish(true);
 }
 
 extern "C" int bfq_fastq_build_ebwt(bfq_ctx *c, const uint8_t *h_fastq, uint64_t len, int term_out, uint8_t *h_bwt,
@@ -774,9 +923,7 @@ extern "C" int bfq_fastq_build_ebwt_fd(bfq_ctx *c, int fastq_fd, uint64_t len, i
 {
     return guarded(c, [&] {
         if (fastq_fd < 0) throw BfqError{BFQ_E_ARG, "bad file descriptor"};
-        fastq_build_ebwt_core(c, TextSrc{HostRef::file(fastq_fd), len}, term_out, bwt_fd >= 0 ? HostRef::file(bwt_fd) : HostRef(),
-                              bwtqs_fd >= 0 ? HostRef::file(bwtqs_fd) : HostRef(), lcp_fd >= 0 ? HostRef::file(lcp_fd) : HostRef(), lcp_bytes,
-                              ~0ull, n_rows, n_reads, true);
+        fastq_build_ebwt_oneshot(c, fastq_fd, len, term_out, bwt_fd, bwtqs_fd, lcp_fd, lcp_bytes, n_rows, n_reads);
     });
 }
 
@@ -926,10 +1073,12 @@ extern "C" int bfq_fastq_run_streams(bfq_ctx *c, const uint8_t *h_fastq, uint64_
 }
 
 static void smooth_invert_fastq_core(bfq_ctx *c, HostRef bwt, HostRef qs, HostRef lcp, int lcp_bytes, uint64_t n, HostRef headers,
-                                     bool haveHeaders, uint64_t headers_len, HostRef out, uint64_t cap, uint64_t *out_len, bfq_stats *st)
+                                     bool haveHeaders, uint64_t headers_len, HostRef out, uint64_t cap, uint64_t *out_len, bfq_stats *st,
+                                     const OutFile *outFile = nullptr)
 {
     SmoothOut r;
     smooth_invert_core(c, bwt, qs, lcp, lcp_bytes, n, 3 * (n + 4096) + 2 * headers_len + (32u << 20), st, &r);
+    if (outFile && outFile->m) bfq_outmap_extend(outFile->m, haveHeaders ? headers_len + 2 * r.total + 4 * r.N : 2 * r.total + 6 * r.N);
     u8 *d_hdr = nullptr;
     if (haveHeaders) {
         d_hdr = c->alloc<u8>(headers_len + 64);
@@ -939,9 +1088,18 @@ static void smooth_invert_fastq_core(bfq_ctx *c, HostRef bwt, HostRef qs, HostRe
     u64 ol = bfq_fastq_format(c, r.ob, r.oq, r.roff, r.N, haveHeaders ? 1 : 0, d_hdr, headers_len, nullptr, &d_out);
     if (out_len) *out_len = ol;
     if (ol > cap) throw BfqError{BFQ_E_ARG, "output buffer smaller than the FASTQ text (see bfq_fastq_out_bound)"};
-    bfq_download(c, out, d_out, ol);
-    c->fetchCounters();
-    c->profCollect();
+    if (outFile) {
+        if (outFile->m && ol > bfq_outmap_len(outFile->m)) throw BfqError{BFQ_E_IO, "output mapping smaller than the FASTQ text"};
+        bfq_write_async(c, outFile->at(0), d_out, ol);
+        c->fetchCounters();
+        c->profCollect();
+        bfq_phase("d2h_write");
+        bfq_write_wait(c);
+    } else {
+        bfq_download(c, out, d_out, ol);
+        c->fetchCounters();
+        c->profCollect();
+    }
     check_counters(c);
     fill_stats(c, st);
 }
@@ -961,9 +1119,22 @@ extern "C" int bfq_smooth_invert_fastq_fd(bfq_ctx *c, int bwt_fd, int qs_fd, int
 {
     return guarded(c, [&] {
         if (bwt_fd < 0 || qs_fd < 0 || out_fd < 0) throw BfqError{BFQ_E_ARG, "bad file descriptor"};
-        smooth_invert_fastq_core(c, HostRef::file(bwt_fd), HostRef::file(qs_fd), lcp_fd >= 0 ? HostRef::file(lcp_fd) : HostRef(), lcp_bytes, n,
-                                 headers_fd >= 0 ? HostRef::file(headers_fd) : HostRef(), headers_fd >= 0, headers_len, HostRef::file(out_fd),
-                                 ~0ull, out_len, st);
+        // the FASTQ text is at least 2 n bytes (bases + qualities + their newlines) and at most 6 n + the header file
+        // (a collection of empty reads): mapped to the bound, pre-faulted to what is certain while the eBWT is uploaded
+        OutFile of;
+        of.open(out_fd, 6 * n + headers_len + 4096, 2 * n);
+        uint64_t ol = 0;
+        try {
+            smooth_invert_fastq_core(c, HostRef::file(bwt_fd), HostRef::file(qs_fd), lcp_fd >= 0 ? HostRef::file(lcp_fd) : HostRef(), lcp_bytes, n,
+                                     headers_fd >= 0 ? HostRef::file(headers_fd) : HostRef(), headers_fd >= 0, headers_len, HostRef::file(out_fd),
+                                     ~0ull, &ol, st, &of);
+        } catch (...) {
+            try { bfq_write_wait(c); } catch (...) {}
+            of.close(0);
+            throw;
+        }
+        if (out_len) *out_len = ol;
+        if (!of.close(ol)) throw BfqError{BFQ_E_IO, "cannot size the output file"};
     });
 }
 

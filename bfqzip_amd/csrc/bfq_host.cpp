@@ -1,0 +1,314 @@
+// bfq_host.cpp -- host-only pieces of libbfqhip.so (no HIP call in this file):
+//   * the per-GPU lease the one-shot tools take (bfq_device_lease): the reference's parallel driver starts n concurrent
+//     `BFQzip.py` children, each of which runs `external/gsufsort/gsufsort` and then `src_int_mem/bfq_int`
+//     (BFQzip_parallel.py:277-285, BFQzip.py:178-228); the drop-in tools must spread over the node's GPUs by themselves,
+//     and never stack several multi-GiB workspaces on one of them;
+//   * the phase timeline the tools print with -V / BFQ_TRACE (bfq_phase, bfq_phase_report): bench.py's dropin_wall_s split;
+//   * background pre-faulting of an output mapping (bfq_prefault_*): the pages of a 9 GB output file on tmpfs are allocated
+//     and zeroed by the kernel at ~6 GB/s; done by helper threads while the GPU works, the final copy runs at memcpy speed.
+#include <errno.h>
+#include <fcntl.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/file.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <time.h>
+#include <unistd.h>
+#include <atomic>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#include "bfq_internal_host.h"
+
+static double now_s()
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+// ---------------------------------------------------------------- environment, read once
+BfqEnv bfq_env_read()
+{
+    {
+        BfqEnv e;
+        auto geti = [](const char *k, int dflt) { const char *v = getenv(k); return (v && *v) ? atoi(v) : dflt; };
+        auto getu = [](const char *k, unsigned long long dflt) {
+            const char *v = getenv(k);
+            if (!v || !*v) return dflt;
+            char *end = nullptr;
+            double x = strtod(v, &end);
+            if (end && (*end == 'G' || *end == 'g')) x *= 1073741824.0;
+            else if (end && (*end == 'M' || *end == 'm')) x *= 1048576.0;
+            else if (end && (*end == 'K' || *end == 'k')) x *= 1024.0;
+            return (unsigned long long)x;
+        };
+        e.trace = getenv("BFQ_TRACE") != nullptr;
+        e.piles = getenv("BFQ_PILES") ? (atoi(getenv("BFQ_PILES")) ? 1 : -1) : 0;
+        e.pilesSplit = getenv("BFQ_PILES_SPLIT") != nullptr;
+        e.noOverlap = getenv("BFQ_NO_OVERLAP") != nullptr;
+        e.noLengthGuess = getenv("BFQ_NO_LENGTH_GUESS") != nullptr;
+        e.posMode = geti("BFQ_POSMODE", 0) != 0;
+        e.invertThreads = geti("BFQ_INVERT_THREADS", 0);
+        e.ioThreads = geti("BFQ_IO_THREADS", 0);
+        e.prefaultThreads = geti("BFQ_PREFAULT_THREADS", -1);
+        e.hugeCap = getu("BFQ_HUGE_CAP", 0);
+        e.wsCap = getu("BFQ_WS_CAP", 0);
+        e.device = getenv("BFQ_DEVICE") ? atoi(getenv("BFQ_DEVICE")) : -1;
+        e.fakeDevices = geti("BFQ_FAKE_DEVICES", 0);
+        e.lease = geti("BFQ_LEASE", 1) != 0;
+        if (const char *d = getenv("BFQ_LEASE_DIR")) e.leaseDir = d;
+        e.invertNt = geti("BFQ_INVERT_NT", 1);
+        e.noOutmap = getenv("BFQ_NO_OUTMAP") != nullptr;
+        return e;
+    }
+}
+const BfqEnv &bfq_env()
+{
+    static const BfqEnv E = bfq_env_read();
+    return E;
+}
+
+// ---------------------------------------------------------------- device lease
+// One lock file per device slot; a slot is held by flock(LOCK_EX) on a descriptor that stays open until
+// bfq_device_release() or the end of the process (the kernel drops the lock with the descriptor, also when the process is
+// killed).  Free slots are tried in order, so eight concurrent tools on an 8-GPU node end up on eight GPUs; when every
+// slot is taken the caller polls until one is released: tools on one GPU run one after the other.
+namespace {
+struct Held { int slot; int fd; std::string path; };
+std::mutex g_leaseMu;
+std::vector<Held> g_held;
+
+std::string lease_dir()
+{
+    const BfqEnv &E = bfq_env();
+    if (!E.leaseDir.empty()) return E.leaseDir;
+    if (access("/dev/shm", W_OK | X_OK) == 0) return "/dev/shm";
+    return "/tmp";
+}
+}   // namespace
+
+extern "C" int bfq_device_lease(int n_slots, const char *const *slot_ids, int only_slot, char *path_out, int path_cap,
+                                double *waited_s)
+{
+    if (n_slots < 1) return BFQ_E_ARG;
+    if (only_slot >= n_slots) return BFQ_E_ARG;
+    const std::string dir = lease_dir();
+    std::vector<int> fds(n_slots, -1);
+    std::vector<std::string> paths(n_slots);
+    const mode_t um = umask(0);                                  // the lock files are shared by every user of the node
+    for (int k = 0; k < n_slots; k++) {
+        if (only_slot >= 0 && k != only_slot) continue;
+        std::string id = (slot_ids && slot_ids[k]) ? slot_ids[k] : ("slot" + std::to_string(k));
+        for (auto &ch : id) if (!((ch >= '0' && ch <= '9') || (ch >= 'a' && ch <= 'z') || (ch >= 'A' && ch <= 'Z') || ch == '.' || ch == '-')) ch = '_';
+        paths[k] = dir + "/bfqzip_amd." + id + ".lock";
+        fds[k] = open(paths[k].c_str(), O_RDWR | O_CREAT | O_CLOEXEC, 0666);
+    }
+    umask(um);
+    int got = -1;
+    const double t0 = now_s();
+    unsigned spin = 0;
+    bool any = false;
+    for (int k = 0; k < n_slots; k++) any = any || fds[k] >= 0;
+    if (!any) return BFQ_E_IO;
+    while (got < 0) {
+        for (int k = 0; k < n_slots && got < 0; k++) {
+            if (fds[k] < 0) continue;
+            if (flock(fds[k], LOCK_EX | LOCK_NB) == 0) got = k;
+            else if (errno != EWOULDBLOCK && errno != EINTR) { close(fds[k]); fds[k] = -1; }
+        }
+        if (got >= 0) break;
+        any = false;
+        for (int k = 0; k < n_slots; k++) any = any || fds[k] >= 0;
+        if (!any) return BFQ_E_IO;
+        const unsigned us = spin < 20 ? 2000 : spin < 100 ? 10000 : 50000;   // 2 ms, then 10 ms, then 50 ms between rounds
+        usleep(us);
+        spin++;
+    }
+    for (int k = 0; k < n_slots; k++)
+        if (k != got && fds[k] >= 0) close(fds[k]);
+    if (waited_s) *waited_s = now_s() - t0;
+    if (path_out && path_cap > 0) { strncpy(path_out, paths[got].c_str(), path_cap - 1); path_out[path_cap - 1] = 0; }
+    {   // who holds it, for people looking at the directory (best effort)
+        char b[64];
+        int l = snprintf(b, sizeof b, "%ld\n", (long)getpid());
+        if (ftruncate(fds[got], 0) == 0) { ssize_t w = pwrite(fds[got], b, (size_t)l, 0); (void)w; }
+    }
+    std::lock_guard<std::mutex> g(g_leaseMu);
+    g_held.push_back(Held{got, fds[got], paths[got]});
+    return got;
+}
+
+extern "C" int bfq_device_release(int slot)
+{
+    std::lock_guard<std::mutex> g(g_leaseMu);
+    for (size_t i = 0; i < g_held.size(); i++)
+        if (g_held[i].slot == slot) {
+            flock(g_held[i].fd, LOCK_UN);
+            close(g_held[i].fd);
+            g_held.erase(g_held.begin() + (long)i);
+            return BFQ_OK;
+        }
+    return BFQ_E_ARG;
+}
+
+// ---------------------------------------------------------------- phase timeline
+namespace {
+struct Phase { std::string name; double secs; };
+std::mutex g_phMu;
+std::vector<Phase> g_phases;
+double g_phT0 = 0, g_phLast = 0;
+int g_phCur = -1;
+bool g_phOn = false;
+double g_startAge = -1;                                          // seconds between exec and the first mark
+
+// seconds since this process was started (exec): /proc/self/stat field 22 against /proc/uptime, 10 ms resolution
+double process_age()
+{
+    FILE *f = fopen("/proc/self/stat", "r");
+    if (!f) return -1;
+    char buf[2048];
+    size_t r = fread(buf, 1, sizeof buf - 1, f);
+    fclose(f);
+    buf[r] = 0;
+    const char *p = strrchr(buf, ')');                           // the command name may contain spaces
+    if (!p) return -1;
+    p++;
+    unsigned long long start = 0;
+    int field = 3;                                               // the next token is field 3 (state); starttime is field 22
+    while (*p && field < 22) { while (*p == ' ') p++; while (*p && *p != ' ') p++; field++; }
+    if (sscanf(p, " %llu", &start) != 1) return -1;
+    double up = 0;
+    f = fopen("/proc/uptime", "r");
+    if (!f) return -1;
+    int ok = fscanf(f, "%lf", &up);
+    fclose(f);
+    if (ok != 1) return -1;
+    const long hz = sysconf(_SC_CLK_TCK);
+    return up - (double)start / (double)(hz > 0 ? hz : 100);
+}
+}   // namespace
+
+extern "C" void bfq_phase_enable(int on)
+{
+    std::lock_guard<std::mutex> g(g_phMu);
+    g_phOn = on != 0;
+}
+extern "C" void bfq_phase(const char *name)
+{
+    std::lock_guard<std::mutex> g(g_phMu);                       // always recorded (a clock read); printed only when asked for
+    const double t = now_s();
+    if (g_phCur < 0 && g_phases.empty()) { g_phT0 = t; g_phLast = t; g_startAge = process_age(); }
+    if (g_phCur >= 0) g_phases[(size_t)g_phCur].secs += t - g_phLast;
+    g_phLast = t;
+    g_phCur = -1;
+    if (!name) return;
+    for (size_t i = 0; i < g_phases.size(); i++)
+        if (g_phases[i].name == name) g_phCur = (int)i;
+    if (g_phCur < 0) { g_phases.push_back(Phase{name, 0}); g_phCur = (int)g_phases.size() - 1; }
+}
+// one line: [bfq phases] {"tool": ..., "exec_to_main": s, "<phase>": s, ..., "total": s}
+extern "C" void bfq_phase_report(const char *tool)
+{
+    bfq_phase(nullptr);
+    std::lock_guard<std::mutex> g(g_phMu);
+    if (g_phases.empty() || !(g_phOn || bfq_env().trace)) return;
+    std::string s = "[bfq phases] {\"tool\": \"";
+    s += tool ? tool : "";
+    s += "\"";
+    char b[128];
+    if (g_startAge >= 0) { snprintf(b, sizeof b, ", \"exec_to_main\": %.3f", g_startAge); s += b; }
+    for (auto &p : g_phases) { snprintf(b, sizeof b, ", \"%s\": %.3f", p.name.c_str(), p.secs); s += b; }
+    snprintf(b, sizeof b, ", \"total\": %.3f}", (g_startAge >= 0 ? g_startAge : 0) + (g_phLast - g_phT0));
+    s += b;
+    fprintf(stderr, "%s\n", s.c_str());
+    fflush(stderr);
+}
+
+// ---------------------------------------------------------------- output mapping + background pre-fault
+struct bfq_outmap {
+    int fd = -1;
+    char *map = nullptr;
+    uint64_t mapLen = 0;
+    std::vector<std::thread> th;
+    std::atomic<uint64_t> next{0};
+    std::atomic<bool> stop{false};
+    std::atomic<uint64_t> preEnd{0};
+    double t0 = 0;
+    std::atomic<uint64_t> done{0};
+};
+static const uint64_t PF_SLICE = 32ull << 20;
+
+static void prefault_worker(bfq_outmap *m)
+{
+    const long pg = sysconf(_SC_PAGESIZE);
+    for (;;) {
+        if (m->stop.load(std::memory_order_relaxed)) return;
+        const uint64_t b = m->next.fetch_add(PF_SLICE);
+        if (b >= m->preEnd) return;
+        const uint64_t pe = m->preEnd.load();
+        const uint64_t e = b + PF_SLICE < pe ? b + PF_SLICE : pe;
+#ifdef MADV_POPULATE_WRITE
+        if (madvise(m->map + b, (size_t)(e - b), MADV_POPULATE_WRITE) == 0) { m->done += e - b; continue; }
+#endif
+        for (uint64_t o = b; o < e; o += (uint64_t)pg) {         // older kernels: touch every page (the file is new: all zero)
+            if (m->stop.load(std::memory_order_relaxed)) return;
+            ((volatile char *)m->map)[o] = 0;
+        }
+        m->done += e - b;
+    }
+}
+
+// Sizes fd to map_len bytes, maps it shared and starts helper threads that fault in [0, prefault_len).  Returns nullptr
+// when the descriptor cannot be mapped (a pipe, /dev/null ...): the caller then writes with pwrite.
+bfq_outmap *bfq_outmap_open(int fd, uint64_t map_len, uint64_t prefault_len)
+{
+    if (fd < 0 || !map_len || bfq_env().noOutmap) return nullptr;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return nullptr;
+    if (ftruncate(fd, (off_t)map_len) != 0) return nullptr;
+    void *p = mmap(nullptr, (size_t)map_len, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (p == MAP_FAILED) { if (ftruncate(fd, 0) != 0) {} return nullptr; }
+    bfq_outmap *m = new bfq_outmap();
+    m->fd = fd; m->map = (char *)p; m->mapLen = map_len;
+    m->preEnd = prefault_len < map_len ? prefault_len : map_len;
+    const uint64_t pe0 = m->preEnd.load();
+    m->t0 = now_s();
+    int T = bfq_env().prefaultThreads;
+    if (T < 0) {
+        const unsigned hw = std::thread::hardware_concurrency();
+        T = hw >= 16 ? 4 : hw >= 8 ? 2 : 1;
+    }
+    if (pe0 < (64ull << 20)) T = 0;                        // small outputs: not worth a thread
+    for (int t = 0; t < T; t++) m->th.emplace_back(prefault_worker, m);
+    return m;
+}
+char *bfq_outmap_ptr(bfq_outmap *m) { return m ? m->map : nullptr; }
+uint64_t bfq_outmap_len(bfq_outmap *m) { return m ? m->mapLen : 0; }
+// more of the file becomes certain (e.g. once the record count is known): extend the pre-fault range
+void bfq_outmap_extend(bfq_outmap *m, uint64_t prefault_len)
+{
+    if (!m) return;
+    if (prefault_len > m->mapLen) prefault_len = m->mapLen;
+    if (prefault_len <= m->preEnd) return;
+    // the workers read preEnd on every slice: raising it keeps those still alive going; finished ones are not restarted
+    // (the copy itself faults in whatever they did not reach)
+    m->preEnd = prefault_len;
+}
+// stops the helpers, unmaps, cuts the file to its final length; false if that failed
+bool bfq_outmap_close(bfq_outmap *m, uint64_t final_len)
+{
+    if (!m) return true;
+    m->stop = true;
+    for (auto &t : m->th) if (t.joinable()) t.join();
+    if (bfq_env().trace)
+        fprintf(stderr, "[bfq io] output mapping %.2f GB: %.2f GB pre-faulted by %zu helper thread(s)\n", final_len / 1e9,
+                (double)m->done.load() / 1e9, m->th.size());
+    bool ok = munmap(m->map, (size_t)m->mapLen) == 0;
+    if (final_len != m->mapLen) ok = (ftruncate(m->fd, (off_t)final_len) == 0) && ok;
+    delete m;
+    return ok;
+}

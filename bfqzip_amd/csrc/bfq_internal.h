@@ -4,10 +4,12 @@
 #include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../include/bfqzip_hip.h"
 #include "bfq_common.h"
+#include "bfq_internal_host.h"
 
 struct BfqError {
     int code;
@@ -64,6 +66,7 @@ struct bfq_ctx {
     hipStream_t stream = nullptr;
     hipStream_t copyStream = nullptr;   // device -> host copies that overlap the tail of the inversion
     bfq_params P;
+    BfqEnv env;                         // the BFQ_* environment as bfq_create() / bfq_set_params() found it
     std::string err;
 
     // workspace arena (bump allocator, reset per top-level call)
@@ -114,6 +117,13 @@ struct bfq_ctx {
     int ioWorkers = 0;
     void ioInit();
     void ioFree();
+    struct BfqWriter *writer = nullptr;  // background device -> host / file writes (bfq_write_async, bfq_io.hip)
+
+    // one-shot tools (the *_fd entry points): the eBWT and its qualities live outside the arena (in the text buffer, whose
+    // FASTQ text is dead once the reads are gathered), so that the arena can be freed while they are still being written;
+    // onRows(start, rows) is called whenever rows [start, start + rows) of the eBWT / QS / LCP are final (pile by pile)
+    u8 *extBwt = nullptr, *extQual = nullptr;
+    std::function<void(u64, u64)> onRows;
 
     // device copy of the FASTQ text of the current call (outside the arena: its record count sizes the arena);
     // kept between calls, grown when a larger text arrives
@@ -136,6 +146,15 @@ void bfq_upload(bfq_ctx *c, void *d_dst, HostRef src, size_t len);
 void bfq_download(bfq_ctx *c, HostRef dst, const void *d_src, size_t len);
 void bfq_upload(bfq_ctx *c, void *d_dst, const void *h_src, size_t len);
 void bfq_download(bfq_ctx *c, void *h_dst, const void *d_src, size_t len);
+// background writes: the bytes [d_src, d_src + len) as they are once the work queued so far on the context's stream has
+// finished go to dst (memory -- e.g. an output mapping -- or a file offset) through the writer's own staging workers; the
+// call returns at once.  bfq_write_wait(): all of them have arrived (throws what went wrong).  d_src must stay valid till then.
+void bfq_write_async(bfq_ctx *c, HostRef dst, const void *d_src, size_t len);
+void bfq_write_wait(bfq_ctx *c);
+// upload on a helper thread while the caller goes on launching kernels; join() waits and rethrows
+struct BfqAsyncUpload;
+BfqAsyncUpload *bfq_upload_begin(bfq_ctx *c, void *d_dst, HostRef src, size_t len);
+void bfq_upload_join(BfqAsyncUpload *u);
 
 #define KLAUNCH(ctx, kid, bytes, kernel, grid, block, ...)                                     \
     do {                                                                                       \

@@ -1,0 +1,37 @@
+// bfq_internal_host.h -- host-only helpers of libbfqhip.so (bfq_host.cpp): no HIP types here.
+#pragma once
+#include <stdint.h>
+#include <string>
+#include "../../include/bfqzip_hip.h"
+
+// The BFQ_* environment variables.  bfq_env(): read once per process (first use) -- tracing, lease, thread counts.
+// A context keeps its own copy, refreshed by bfq_create() and bfq_set_params() only (test knobs change between calls).
+struct BfqEnv {
+    bool trace = false;             // BFQ_TRACE: phase timeline, transfer rates, workspace allocations on stderr
+    int piles = 0;                  // BFQ_PILES=1/0: step 1 pile by pile always / never (overrides bfq_params.piles); unset: 0
+    bool pilesSplit = false;        // BFQ_PILES_SPLIT: every pile once more by its second symbol (test knob)
+    bool noOverlap = false;         // BFQ_NO_OVERLAP: inversion and device -> host copies one after the other
+    bool noLengthGuess = false;     // BFQ_NO_LENGTH_GUESS: always count read lengths by LF walks
+    bool posMode = false;           // BFQ_POSMODE=1: steps 3-4 without LF table (position mode)
+    int invertThreads = 0;          // BFQ_INVERT_THREADS: workgroup size of k_invert (0: default)
+    int ioThreads = 0;              // BFQ_IO_THREADS: staging workers (0: by core count)
+    int prefaultThreads = -1;       // BFQ_PREFAULT_THREADS: helpers that fault in output mappings (-1: by core count)
+    unsigned long long hugeCap = 0; // BFQ_HUGE_CAP: slot budget of the huge-segment rounds (test knob)
+    unsigned long long wsCap = 0;   // BFQ_WS_CAP: upper bound of the device workspace in bytes (suffixes K/M/G), 0: none
+    int device = -1;                // BFQ_DEVICE: the GPU the one-shot tools use (-1: first free one, by lease)
+    int fakeDevices = 0;            // BFQ_FAKE_DEVICES=n: pretend n GPUs (slot k -> device k mod the real count): lease tests on one GPU
+    bool lease = true;              // BFQ_LEASE=0: no lease files (the caller places the tools itself)
+    std::string leaseDir;           // BFQ_LEASE_DIR: where the lock files live (default /dev/shm, else /tmp)
+    bool noOutmap = false;          // BFQ_NO_OUTMAP: the tools write their outputs with pwrite instead of through a mapping (test knob)
+    int invertNt = 1;               // BFQ_INVERT_NT=0: plain instead of nontemporal LF-table loads in k_invert
+};
+BfqEnv bfq_env_read();
+const BfqEnv &bfq_env();
+
+// output file mapped for writing, pre-faulted in the background
+struct bfq_outmap;
+bfq_outmap *bfq_outmap_open(int fd, uint64_t map_len, uint64_t prefault_len);
+char *bfq_outmap_ptr(bfq_outmap *m);
+uint64_t bfq_outmap_len(bfq_outmap *m);
+void bfq_outmap_extend(bfq_outmap *m, uint64_t prefault_len);
+bool bfq_outmap_close(bfq_outmap *m, uint64_t final_len);

@@ -27,7 +27,7 @@
 static int io_threads()
 {
     static const int t = [] {
-        if (const char *e = getenv("BFQ_IO_THREADS")) { int v = atoi(e); if (v >= 1 && v <= BFQ_IO_MAX_WORKERS) return v; }
+        { int v = bfq_env().ioThreads; if (v >= 1 && v <= BFQ_IO_MAX_WORKERS) return v; }
         unsigned hw = std::thread::hardware_concurrency();
         int v = hw >= 32 ? 8 : hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
         return v;
@@ -66,8 +66,10 @@ void bfq_ctx::ioInit()
     }
     ioWorkers = T;
 }
+static void writer_free(bfq_ctx *c);
 void bfq_ctx::ioFree()
 {
+    writer_free(this);
     for (int t = 0; t < BFQ_IO_MAX_WORKERS; t++) {
         IoWorker &w = io[t];
         if (w.stream) { (void)hipStreamSynchronize(w.stream); (void)hipStreamDestroy(w.stream); w.stream = nullptr; }
@@ -107,7 +109,7 @@ static bool host_put(const HostRef &h, size_t off, const char *src, size_t sz)
 }
 
 // Chunk i of the transfer belongs to worker i mod T.  `up`: host -> device, else device -> host.
-static bool io_trace() { static const bool t = getenv("BFQ_TRACE") != nullptr; return t; }
+static bool io_trace() { return bfq_env().trace; }
 static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
 static void staged_copy(bfq_ctx *c, char *dev, HostRef host, size_t len, bool up)
@@ -210,6 +212,190 @@ void bfq_download(bfq_ctx *c, HostRef dst, const void *d_src, size_t len)
     staged_copy(c, (char *)d_src, dst, len, false);
 }
 void bfq_download(bfq_ctx *c, void *h_dst, const void *d_src, size_t len) { bfq_download(c, HostRef::mem(h_dst), d_src, len); }
+
+// ---------------------------------------------------------------- background writes (one-shot tools)
+// The drop-in tools write 9 GB files (BFQzip.py:184,215-222 at 30 M x 150 bp).  Their outputs leave the device while the GPU
+// is still working on the next pile / chunk: a few writer threads, each with its own stream and two pinned staging buffers,
+// take 16 MiB pieces from a queue -- DMA into one buffer while the other is copied into the (pre-faulted) output mapping.
+#include <condition_variable>
+#include <deque>
+#include <exception>
+#include <mutex>
+struct WrTask { HostRef dst; const char *src; size_t sz; hipEvent_t after; };
+struct BfqWriter {
+    bfq_ctx *c = nullptr;
+    bfq_ctx::IoWorker w[BFQ_IO_MAX_WORKERS];
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, cvIdle;
+    std::deque<WrTask> q;
+    size_t inflight = 0;                                        // queued or staged, not yet at their destination
+    bool quit = false;
+    hipError_t err = hipSuccess;
+    bool ioFail = false;
+    std::vector<hipEvent_t> events;
+    double bytes = 0, t0 = 0;
+};
+static void writer_thread(BfqWriter *W, int t)
+{
+    bfq_ctx::IoWorker &w = W->w[t];
+    hipError_t e = hipSetDevice(W->c->device);
+    WrTask pend[2];
+    pend[0].sz = pend[1].sz = 0;
+    auto flush = [&](int k) {
+        if (!pend[k].sz) return;
+        hipError_t fe = hipEventSynchronize(w.done[k]);
+        bool bad = false;
+        if (fe == hipSuccess) bad = !host_put(pend[k].dst, 0, w.stage[k], pend[k].sz);
+        pend[k].sz = 0;
+        std::lock_guard<std::mutex> g(W->mu);
+        if (fe != hipSuccess && W->err == hipSuccess) W->err = fe;
+        if (bad) W->ioFail = true;
+        W->inflight--;
+        W->cvIdle.notify_all();
+    };
+    int k = 0;
+    for (;;) {
+        WrTask task;
+        {
+            std::unique_lock<std::mutex> lk(W->mu);
+            if (W->q.empty() && (pend[0].sz || pend[1].sz)) { lk.unlock(); flush(k ^ 1); flush(k); continue; }
+            W->cv.wait(lk, [&] { return W->quit || !W->q.empty(); });
+            if (W->q.empty()) break;                            // quit
+            task = W->q.front();
+            W->q.pop_front();
+        }
+        flush(k);                                               // stage[k] is free again
+        if (e == hipSuccess && task.after) e = hipStreamWaitEvent(w.stream, task.after, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(w.stage[k], task.src, task.sz, hipMemcpyDeviceToHost, w.stream);
+        if (e == hipSuccess) e = hipEventRecord(w.done[k], w.stream);
+        if (e != hipSuccess) {
+            std::lock_guard<std::mutex> g(W->mu);
+            if (W->err == hipSuccess) W->err = e;
+            W->inflight--;
+            W->cvIdle.notify_all();
+            e = hipSuccess;
+            (void)hipGetLastError();
+            continue;
+        }
+        pend[k] = task;
+        flush(k ^ 1);                                           // the other buffer drains while this DMA runs
+        k ^= 1;
+    }
+    flush(0); flush(1);
+}
+static BfqWriter *writer_get(bfq_ctx *c)
+{
+    if (c->writer) return c->writer;
+    BfqWriter *W = new BfqWriter();
+    W->c = c;
+    const int T = io_threads();
+    for (int t = 0; t < T; t++) {
+        HIP_CHECK(hipStreamCreateWithFlags(&W->w[t].stream, hipStreamNonBlocking));
+        for (int k = 0; k < 2; k++) {
+            HIP_CHECK(hipHostMalloc((void **)&W->w[t].stage[k], BFQ_IO_STAGE_BYTES, hipHostMallocDefault));
+            HIP_CHECK(hipEventCreateWithFlags(&W->w[t].done[k], hipEventDisableTiming));
+        }
+    }
+    c->writer = W;
+    for (int t = 0; t < T; t++) W->th.emplace_back(writer_thread, W, t);
+    return W;
+}
+void bfq_write_async(bfq_ctx *c, HostRef dst, const void *d_src, size_t len)
+{
+    if (!len) return;
+    BfqWriter *W = writer_get(c);
+    hipEvent_t ev;
+    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_CHECK(hipEventRecord(ev, c->stream));
+    const size_t CH = BFQ_IO_STAGE_BYTES;
+    std::lock_guard<std::mutex> g(W->mu);
+    if (!W->inflight && W->bytes == 0) W->t0 = now_s();
+    W->events.push_back(ev);
+    for (size_t off = 0; off < len; off += CH) {
+        WrTask t;
+        t.dst = dst;
+        if (dst.ptr) t.dst.ptr = (char *)dst.ptr + off; else t.dst.off = dst.off + off;
+        t.src = (const char *)d_src + off;
+        t.sz = std::min(CH, len - off);
+        t.after = ev;
+        W->q.push_back(t);
+        W->inflight++;
+    }
+    W->bytes += (double)len;
+    W->cv.notify_all();
+}
+void bfq_write_wait(bfq_ctx *c)
+{
+    BfqWriter *W = c->writer;
+    if (!W) return;
+    hipError_t e;
+    bool bad;
+    {
+        std::unique_lock<std::mutex> lk(W->mu);
+        W->cvIdle.wait(lk, [&] { return W->inflight == 0; });
+        e = W->err; bad = W->ioFail;
+        W->err = hipSuccess; W->ioFail = false;
+        for (auto ev : W->events) (void)hipEventDestroy(ev);
+        W->events.clear();
+        if (io_trace() && W->bytes > 0)
+            fprintf(stderr, "[bfq io] background writes: %.2f GB, last byte %.3f s after the first was queued\n", W->bytes / 1e9, now_s() - W->t0);
+        W->bytes = 0;
+    }
+    if (e != hipSuccess) throw BfqError{BFQ_E_HIP, std::string("background write: ") + hipGetErrorString(e)};
+    if (bad) throw BfqError{BFQ_E_IO, std::string("background write: file write failed: ") + strerror(errno)};
+}
+static void writer_free(bfq_ctx *c)
+{
+    BfqWriter *W = c->writer;
+    if (!W) return;
+    {
+        std::lock_guard<std::mutex> g(W->mu);
+        W->quit = true;
+        W->cv.notify_all();
+    }
+    for (auto &t : W->th) t.join();
+    for (auto ev : W->events) (void)hipEventDestroy(ev);
+    for (int t = 0; t < BFQ_IO_MAX_WORKERS; t++) {
+        bfq_ctx::IoWorker &w = W->w[t];
+        if (w.stream) { (void)hipStreamSynchronize(w.stream); (void)hipStreamDestroy(w.stream); }
+        for (int k = 0; k < 2; k++) {
+            if (w.stage[k]) (void)hipHostFree(w.stage[k]);
+            if (w.done[k]) (void)hipEventDestroy(w.done[k]);
+        }
+    }
+    delete W;
+    c->writer = nullptr;
+}
+
+// upload on a helper thread (the staging workers do the copying; the caller's thread stays free to launch kernels)
+struct BfqAsyncUpload { std::thread th; std::exception_ptr ex; BfqError err{0, ""}; bool failed = false; };
+BfqAsyncUpload *bfq_upload_begin(bfq_ctx *c, void *d_dst, HostRef src, size_t len)
+{
+    BfqAsyncUpload *u = new BfqAsyncUpload();
+    if (!len) return u;
+    c->ioInit();                                                // on the caller's thread: no race with a later ioInit()
+    for (int t = 0; t < c->ioWorkers; t++)
+        for (int k = 0; k < 2; k++)
+            if (!c->io[t].done[k]) HIP_CHECK(hipEventCreateWithFlags(&c->io[t].done[k], hipEventDisableTiming));
+    u->th = std::thread([=] {
+        try { (void)hipSetDevice(c->device); staged_copy(c, (char *)d_dst, src, len, true); }
+        catch (const BfqError &e) { u->err = e; u->failed = true; }
+        catch (...) { u->ex = std::current_exception(); }
+    });
+    return u;
+}
+void bfq_upload_join(BfqAsyncUpload *u)
+{
+    if (!u) return;
+    if (u->th.joinable()) u->th.join();
+    const bool failed = u->failed;
+    const BfqError err = u->err;
+    std::exception_ptr ex = u->ex;
+    delete u;
+    if (failed) throw err;
+    if (ex) std::rethrow_exception(ex);
+}
 
 // ---------------------------------------------------------------- host-side line index
 // counts[i] = number of '\n' in bytes [i*chunk, (i+1)*chunk) of the text

@@ -48,6 +48,7 @@ static void help()
 
 int main(int argc, char **argv)
 {
+    bfq_phase("start");
     std::string in_dna, in_qual, in_lcp, output, titles;
     int K = -1, m = 0, v = 0, f = 0, t = -1, term = '#';
     bool headers = false, verbose = false;
@@ -68,7 +69,7 @@ int main(int argc, char **argv)
         case 't': t = atoi(optarg); break;
         case 's': term = atoi(optarg); break;
         case 'D': break;                       // debug dump: unusable in the reference
-        case 'V': verbose = true; break;
+        case 'V': verbose = true; bfq_phase_enable(1); break;
         case 'H': titles = optarg; headers = true; break;
         default: help(); return -1;
         }
@@ -114,8 +115,8 @@ int main(int argc, char **argv)
         }
     }
     uint64_t n = bwt.size;
-    bfq_ctx *c = bfq_create(0, &P);
-    if (!c) { fprintf(stderr, "%s: %s\n", TOOL, bfq_create_error()); return 1; }
+    bfq_ctx *c = create_on_free_gpu(TOOL, &P);
+    if (!c) return 1;
     // the FASTQ text (header line verbatim from -H, else "@"; bases; "+"; qualities -- bfq_int.cpp:797-810)
     // is laid out on the GPU and written straight from the library's staging buffers
     if (headers && !hdr.open(titles)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, titles.c_str()); return 1; }
@@ -130,8 +131,11 @@ int main(int argc, char **argv)
         bfq_destroy(c);
         return 1;
     }
+    bfq_phase("teardown");
+    const bool closed = outText.close();
     bfq_destroy(c);
-    if (!outText.close()) { perror("invert"); return 1; }
+    if (!closed) { perror("invert"); return 1; }
+    bfq_phase_report(TOOL);
     const uint64_t N = st.n_reads;
     printf("Number of reads: %llu\n", (unsigned long long)N);
 

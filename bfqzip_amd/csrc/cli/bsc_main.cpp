@@ -18,8 +18,8 @@ int main(int argc, char **argv)
         memcpy(&rows, bz.data() + 8, 8);
         bfq_params P;
         bfq_default_params(&P);
-        bfq_ctx *c = bfq_create(0, &P);
-        if (!c) { fprintf(stderr, "bsc: %s\n", bfq_create_error()); return 1; }
+        bfq_ctx *c = create_on_free_gpu("bsc", &P);
+        if (!c) return 1;
         std::vector<uint8_t> dna(rows + 1), qs(rows + 1);
         uint64_t sl = 0, nr = 0;
         const int rc = bfq_stream_ebwt_decode(c, bz.data(), bz.size(), qz.data(), qz.size(), dna.data(), qs.data(), rows, &sl, &nr);
@@ -38,8 +38,8 @@ int main(int argc, char **argv)
     if (!read_file(argv[2], in)) { fprintf(stderr, "bsc: cannot read %s\n", argv[2]); return 1; }
     bfq_params P;
     bfq_default_params(&P);
-    bfq_ctx *c = bfq_create(0, &P);
-    if (!c) { fprintf(stderr, "bsc: %s\n", bfq_create_error()); return 1; }
+    bfq_ctx *c = create_on_free_gpu("bsc", &P);
+    if (!c) return 1;
     uint64_t cap;
     if (enc) cap = bfq_stream_bound(in.size());
     else {

@@ -15,6 +15,7 @@ int main(int argc, char **argv)
     const char *tool = "gsufsort";
     int term = '#';
 #endif
+    bfq_phase("start");
     std::string in, out;
     bool wantLcp = false;
     int lbytes = 1;
@@ -24,6 +25,7 @@ int main(int argc, char **argv)
         else if (a == "--mem" || a == "-m" || a == "--docs" || a == "-d") { ++i; }
         else if (a == "--lbytes") { if (++i < argc) lbytes = atoi(argv[i]); }
         else if (a == "--lcp") wantLcp = true;
+        else if (a == "-v" || a == "--verbose") bfq_phase_enable(1);
         else if (a.size() && a[0] == '-') { /* --bwt --qs --em --rev ...: accepted, nothing to do */ }
         else if (in.empty()) in = a;
     }
@@ -37,8 +39,8 @@ int main(int argc, char **argv)
     bfq_params P;
     bfq_default_params(&P);
     P.piles = 1;                                 // one process, one collection: the smaller pile-by-pile workspace is allocated faster
-    bfq_ctx *c = bfq_create(0, &P);
-    if (!c) { fprintf(stderr, "%s: %s\n", tool, bfq_create_error()); return 1; }
+    bfq_ctx *c = create_on_free_gpu(tool, &P);
+    if (!c) return 1;
     uint64_t n = 0, N = 0;
     OutFile bwt, qs, lcpf;
     bool ok = bwt.open(out + ".bwt") && qs.open(out + ".bwt.qs");
@@ -46,10 +48,12 @@ int main(int argc, char **argv)
     if (!ok) { fprintf(stderr, "%s: cannot create outputs for %s\n", tool, out.c_str()); bfq_destroy(c); return 1; }
     int rc = bfq_fastq_build_ebwt_fd(c, buf.fd, buf.size, term, bwt.fd, qs.fd, wantLcp ? lcpf.fd : -1, lbytes, &n, &N);
     if (rc) { fprintf(stderr, "%s: %s: %s\n", tool, in.c_str(), bfq_last_error(c)); bfq_destroy(c); return 1; }
-    bfq_destroy(c);
+    bfq_phase("teardown");
     ok = bwt.close() && qs.close();
     ok = lcpf.close() && ok;
+    bfq_destroy(c);
     if (!ok) { fprintf(stderr, "%s: cannot write outputs for %s\n", tool, out.c_str()); return 1; }
+    bfq_phase_report(tool);
     printf("%s (bfqzip_amd/gfx950): %llu reads, %llu eBWT symbols -> %s.bwt, %s.bwt.qs%s\n", tool, (unsigned long long)N,
            (unsigned long long)n, out.c_str(), out.c_str(), wantLcp ? " (+lcp)" : "");
     return 0;

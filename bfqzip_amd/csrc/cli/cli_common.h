@@ -42,6 +42,21 @@ static inline bool file_exists(const std::string &p)
 #include <sys/stat.h>
 #include <unistd.h>
 
+// The GPU this process uses: the first one nobody else holds (per-GPU lease files, include/bfqzip_hip.h), so that the n
+// concurrent children of an unchanged BFQzip_parallel.py (:277-285) spread over the node's GPUs; $BFQ_DEVICE pins it.
+static inline bfq_ctx *create_on_free_gpu(const char *tool, const bfq_params *P)
+{
+    bfq_phase("lease");
+    char info[320] = {0};
+    const int dev = bfq_pick_device(info, sizeof info);
+    if (dev < 0) { fprintf(stderr, "%s: no GPU to run on (bfq_pick_device: %d)\n", tool, dev); return nullptr; }
+    if (getenv("BFQ_TRACE")) fprintf(stderr, "[bfq lease] %s pid %ld: %s\n", tool, (long)getpid(), info);
+    bfq_phase("hip_init");
+    bfq_ctx *c = bfq_create(dev, P);
+    if (!c) fprintf(stderr, "%s: %s\n", tool, bfq_create_error());
+    return c;
+}
+
 struct InFile {
     int fd = -1;
     uint64_t size = 0;

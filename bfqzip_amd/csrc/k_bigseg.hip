@@ -186,7 +186,7 @@ void bfq_refine_huge(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp,
     char *side = nullptr;
     char *const ws0 = c->ws;
     const size_t cap0 = c->wsCap, top0 = c->wsTop;
-    if (cap < maxLen && !getenv("BFQ_HUGE_CAP")) {
+    if (cap < maxLen && !c->env.hugeCap) {
         size_t freeB = 0, totalB = 0;
         HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
         size_t want = fixed + (size_t)std::min<u64>(hc[1], 1ull << 31) * HUGE_BYTES_PER_SLOT;
@@ -205,10 +205,7 @@ void bfq_refine_huge(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp,
         ~Restore() { if (side) { (void)hipStreamSynchronize(c->stream); (void)hipFree(side); c->ws = ws; c->wsCap = cap; c->wsTop = top; } }
     } restore{c, ws0, cap0, top0, side};
     if (cap > (1ull << 31)) cap = 1ull << 31;          // slot numbers and sub-segment ids are 32-bit sort keys
-    if (const char *e = getenv("BFQ_HUGE_CAP")) {      // test hook: exercise batching and the oversize route on small inputs
-        u64 v = strtoull(e, nullptr, 10);
-        if (v < cap) cap = v;
-    }
+    if (c->env.hugeCap && c->env.hugeCap < cap) cap = c->env.hugeCap;   // BFQ_HUGE_CAP, test hook: exercise batching and the oversize route on small inputs
     std::vector<u64> overS, overL;
     u64 i = 0;
     while (i < nh) {

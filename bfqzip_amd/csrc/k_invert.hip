@@ -110,7 +110,7 @@ void bfq_invert(bfq_ctx *c, const RankIndex &R, u64 N, const u64 *d_roff, int B,
 {
     if (count == ~0ull) count = N - first;
     if (!count) return;
-    static const int nt = getenv("BFQ_INVERT_NT") ? atoi(getenv("BFQ_INVERT_NT")) : 1;   // nt loads: -15% (L1 bypass)
+    const int nt = c->env.invertNt;                      // nontemporal loads: -15% (L1 bypass)
     const double bytes = 68.0 * (double)(R.n - N) * ((double)count / (double)N);
 #define INV_LAUNCH(NTV, NLV) KLAUNCH(c, K_INVERT, bytes, (k_invert<NTV, NLV>), bfq_grid(count, 256), 256, R, first, count, d_roff, B, out_bases, out_quals, c->d_cnt)
     if (nt) { if (lines) INV_LAUNCH(1, 1); else INV_LAUNCH(1, 0); }

@@ -167,8 +167,8 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     const u64 n = total + N;
     if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^37 rows)"};
     c->n = n; c->N = N;
-    c->d_bwt = c->alloc<u8>(n + 64);
-    c->d_qual = c->alloc<u8>(n + 64);
+    c->d_bwt = c->extBwt ? c->extBwt : c->alloc<u8>(n + 64);
+    c->d_qual = c->extQual ? c->extQual : c->alloc<u8>(n + 64);
     c->d_lcp = c->alloc<u16>(n + 64);
     c->d_gcnt = nullptr; c->gcntTerm = -1;                       // symbol counts per group are not produced pile by pile
     if (!n) return;
@@ -190,6 +190,7 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     if (tot[0] != N) throw BfqError{BFQ_E_ARG, "pile counts do not match the collection"};
     if (N) KLAUNCH(c, K_EMIT, 12.0 * (double)N, k_term_pile, bfq_grid(N, 256), 256, (const u8 *)T8, (const u8 *)Q8, d_roff, N,
                    (u32)(termOut & 0xFF), c->d_bwt, c->d_qual, c->d_lcp);
+    if (c->onRows) c->onRows(0, N);
     const size_t avail = c->wsCap - c->wsTop;
     auto fits = [&](u64 m) { return (size_t)(24 * (m + 256) + 12 * 256 * (ceil_div(m + 1, bfq_radix_block_elems(m)) + 8) + (m / 32768 + 4096) * 64 + (48u << 20)) <= avail; };
     // one pile (first symbol s, second symbol s2 or 7 = any) of m suffixes -> rows [start, start + m)
@@ -212,7 +213,7 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     for (u32 s = 1; s <= 5; s++) {
         const u64 m = tot[s];
         if (!m) continue;
-        if (fits(m) && !getenv("BFQ_PILES_SPLIT")) { run_pile(s, 7u, m, start, blkOff + (u64)s * nb); start += m; continue; }
+        if (fits(m) && !c->env.pilesSplit) { run_pile(s, 7u, m, start, blkOff + (u64)s * nb); if (c->onRows) c->onRows(start, m); start += m; continue; }
         // a pile beyond the workspace (skewed base composition, low-complexity reads): once more by its second symbol
         const size_t ms = c->mark();
         u32 *cnt2 = c->alloc<u32>(6 * nb);
@@ -240,6 +241,7 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
                 c->sync();
             }
             firstSub = false;
+            if (c->onRows) c->onRows(start, m2);
             start += m2;
         }
         c->release(ms);

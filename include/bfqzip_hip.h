@@ -69,6 +69,29 @@ const char *bfq_last_error(bfq_ctx *c);
 void    *bfq_stream(bfq_ctx *c);                                /* the hipStream_t all kernels run on */
 int      bfq_device_count(void);
 
+/* ---- which GPU a one-shot tool uses.  BFQzip_parallel.py:277-285 starts n concurrent `BFQzip.py` children whose
+ * gsufsort / bfq_int processes know nothing of each other (BFQzip.py:178-228): the drop-in tools spread over the node's GPUs
+ * through per-GPU lease files -- `<dir>/bfqzip_amd.<PCI bus id>.lock`, held by flock() until the process ends; dir =
+ * $BFQ_LEASE_DIR, else /dev/shm, else /tmp.  bfq_pick_device() takes the first free GPU (polling when all are busy, so tools
+ * on one GPU run one after the other instead of stacking their workspaces) and returns its device index for bfq_create(),
+ * or a negative BFQ_E_* code.  $BFQ_DEVICE=k pins the tool to GPU k (still under that GPU's lease); $BFQ_LEASE=0 switches the
+ * lease off (device $BFQ_DEVICE or 0); $BFQ_FAKE_DEVICES=n pretends n GPUs (slot k -> device k mod the real count; lease tests
+ * on one GPU).  info (may be NULL) receives "device <k> lease <path> waited <s> s".  Long-lived hosts (parallel.py, bench.py)
+ * place their ranks themselves and never call it.
+ * bfq_device_lease() is the host-only part (no GPU needed): n_slots lock files named by slot_ids[k] (NULL: "slot<k>"),
+ * only_slot >= 0 restricts the choice to that slot; returns the slot taken.  bfq_device_release() gives a slot back early. */
+int bfq_pick_device(char *info, int info_cap);
+int bfq_device_lease(int n_slots, const char *const *slot_ids, int only_slot, char *path_out, int path_cap, double *waited_s);
+int bfq_device_release(int slot);
+
+/* ---- phase timeline of a one-shot tool (process + HIP start, lease wait, allocation, file read + H2D, GPU, D2H + file
+ * write): bfq_phase(name) closes the running phase and opens `name` (NULL: closes only); bfq_phase_report(tool) prints one
+ * line `[bfq phases] {"tool": .., "exec_to_main": s, "<phase>": s, .., "total": s}` on stderr.  Off unless
+ * bfq_phase_enable(1) was called (the tools' -V) or $BFQ_TRACE is set; bench.py's dropin_wall_s split is parsed from it. */
+void bfq_phase_enable(int on);
+void bfq_phase(const char *name);
+void bfq_phase_report(const char *tool);
+
 /* ---- step 1: replaces `gsufsort <fq> --bwt --qs -o OUT` (BFQzip.py:184) and
  *      `eGap <fq> --em --mem M --qs -o OUT --lcp --lbytes 1` (BFQzip_ext.py:177).
  * h_bases/h_quals: the reads back to back (lines 2 and 4 of each record),

@@ -85,3 +85,97 @@ def test_shared_host_device_helpers(tmp_path):
     subprocess.check_call(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cxx", "test_common.cpp")])
     r = subprocess.run([exe], stdout=subprocess.PIPE, timeout=120)
     assert r.returncode == 0, r.stdout.decode()[-2000:]
+
+
+# ---- per-GPU lease of the one-shot tools (bfq_device_lease: host only, no GPU needed).  BFQzip_parallel.py:277-285
+# starts n concurrent children; each must end up on a GPU of its own, and never two on one.
+_LEASE_CHILD = r"""
+import ctypes as C, os, sys, time
+L = C.CDLL({lib!r})                     # no torch import: the children must start within milliseconds of each other
+L.bfq_device_lease.argtypes = [C.c_int, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double)]
+path = C.create_string_buffer(300); waited = C.c_double(0)
+ids = (C.c_char_p * {n})(*[("t%d" % k).encode() for k in range({n})])
+t0 = time.time()
+slot = L.bfq_device_lease({n}, ids, {only}, path, 300, C.byref(waited))
+t1 = time.time()
+print("GOT", slot, path.value.decode(), "%.3f" % t0, "%.3f" % t1, "%.3f" % waited.value, flush=True)
+time.sleep({hold})
+if {release}:
+    assert L.bfq_device_release(slot) == 0
+    print("REL", "%.3f" % time.time(), flush=True)
+    time.sleep(0.3)
+print("END", "%.3f" % time.time(), flush=True)
+"""
+
+
+def _lease_children(tmp_path, n_slots, n_children, hold, only=-1, release=0, stagger=0.0):
+    import subprocess, sys, time
+    env = dict(os.environ, BFQ_LEASE_DIR=str(tmp_path))
+    code = _LEASE_CHILD.format(lib=_lib.LIB_PATH, n=n_slots, only=only, hold=hold, release=release)
+    ps = []
+    for _ in range(n_children):
+        ps.append(subprocess.Popen([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, text=True))
+        if stagger:
+            time.sleep(stagger)
+    outs = []
+    for p in ps:
+        o, _ = p.communicate(timeout=120)
+        assert p.returncode == 0, o
+        rec = {}
+        for line in o.splitlines():
+            f = line.split()
+            if f and f[0] == "GOT":
+                rec.update(slot=int(f[1]), path=f[2], t_ask=float(f[3]), t_got=float(f[4]), waited=float(f[5]))
+            elif f and f[0] in ("REL", "END"):
+                rec[f[0].lower()] = float(f[1])
+        outs.append(rec)
+    return outs
+
+
+def test_device_lease_spreads_concurrent_tools(tmp_path):
+    """Two concurrent holders with two slots take different slots and neither waits."""
+    r = _lease_children(tmp_path, 2, 2, hold=1.5)
+    assert sorted(x["slot"] for x in r) == [0, 1]
+    assert len({x["path"] for x in r}) == 2 and all(str(tmp_path) in x["path"] for x in r)
+    assert all(x["waited"] < 1.0 for x in r)
+
+
+def test_device_lease_serialises_on_one_slot(tmp_path):
+    """With a single slot the second tool waits until the first process has ended (the kernel drops the lock with it)."""
+    r = _lease_children(tmp_path, 1, 2, hold=1.0, stagger=0.3)
+    assert [x["slot"] for x in r] == [0, 0]
+    first, second = sorted(r, key=lambda x: x["t_got"])
+    assert second["t_got"] >= first["end"] - 0.05 and second["waited"] > 0.3
+
+
+def test_device_lease_more_tools_than_slots_and_release(tmp_path):
+    """Three tools, two slots: the third gets whichever slot is given back first (bfq_device_release), not a fixed one."""
+    r = _lease_children(tmp_path, 2, 3, hold=0.8, release=1, stagger=0.15)
+    got = sorted(r, key=lambda x: x["t_got"])
+    assert sorted(x["slot"] for x in got[:2]) == [0, 1]
+    assert got[2]["waited"] > 0.2 and got[2]["t_got"] >= min(got[0]["rel"], got[1]["rel"]) - 0.05
+
+
+def test_device_lease_pinned_slot(tmp_path):
+    """only_slot (BFQ_DEVICE): both tools ask for slot 1 of 4 and run one after the other on it."""
+    r = _lease_children(tmp_path, 4, 2, hold=0.7, only=1, stagger=0.2)
+    assert [x["slot"] for x in r] == [1, 1]
+    first, second = sorted(r, key=lambda x: x["t_got"])
+    assert second["t_got"] >= first["end"] - 0.05
+    L = _lib.lib()
+    assert L.bfq_device_lease(0, None, -1, None, 0, None) == -1 and L.bfq_device_lease(2, None, 2, None, 0, None) == -1
+
+
+def test_phase_report_line(tmp_path):
+    """The tools' -V / BFQ_TRACE timeline: one JSON object per process on stderr, phases in order of first use."""
+    import json, subprocess, sys
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from bfqzip_amd import _lib\nL = _lib.lib()\nL.bfq_phase_enable(1)\n"
+            "L.bfq_phase(b'start'); time.sleep(0.05); L.bfq_phase(b'gpu'); time.sleep(0.1); L.bfq_phase(b'start'); time.sleep(0.05)\n"
+            "L.bfq_phase_report(b'tool')\n") % ROOT
+    p = subprocess.run([sys.executable, "-c", code], stderr=subprocess.PIPE, text=True, timeout=120)
+    line = [x for x in p.stderr.splitlines() if x.startswith("[bfq phases] ")]
+    assert len(line) == 1, p.stderr
+    d = json.loads(line[0][len("[bfq phases] "):])
+    assert list(d)[:2] == ["tool", "exec_to_main"] and list(d)[2:] == ["start", "gpu", "total"]
+    assert 0.08 <= d["start"] <= 0.5 and 0.08 <= d["gpu"] <= 0.5 and d["total"] >= d["start"] + d["gpu"] and d["exec_to_main"] >= 0
