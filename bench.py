@@ -55,6 +55,30 @@ def pmc_traffic(kernel, rows):
     return round((fetch + k["write_B_per_row"]) * rows)
 
 
+def pmc_traffic_per_row():
+    """Sum over the step's kernels of the PMC-measured HBM bytes per row (the newest profiles/*/traffic_per_row.json)."""
+    import glob
+    best = None
+    for p in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "traffic_per_row.json"))):
+        try:
+            best = json.load(open(p))
+        except Exception:
+            pass
+    if not best:
+        return None
+    if "step_total_B_per_row" in best:
+        return best["step_total_B_per_row"]
+    ks = best.get("kernels", {})
+    steps = ks.get("k_refine_chunk", {}).get("calls")
+    if not steps:
+        return None
+    tot = 0.0
+    for name, k in ks.items():
+        streaming = name.split("<")[0] not in ("k_invert", "k_refine_chunk", "k_cluster")
+        tot += (k["fetch_B_per_row_raw"] * (2.0 if streaming else 1.0) + k["write_B_per_row"]) * k["calls"] / steps
+    return tot
+
+
 def parse_workload(w):
     a, b = w.lower().split("x")
     mult = 1
@@ -186,7 +210,7 @@ def stream_codec(api, eng, outs, lens, N, L, log, with_cpu, text=None):
                                      "bytes_in": int(len(text)), "bytes_out": int(len(z.dna) + len(z.qs) + len(z.hdr)),
                                      "containers_equal_separate_run": bool(same),
                                      "what": "bfq_fastq_run_job with compress_streams: FASTQ text (pinned) -> parse, eBWT, clusters, inversion, "
-                                             "entropy coding, all on the GPU -> three BFQRANS1 containers (pinned); the raw streams never cross the bus"}
+                                             "entropy coding, all on the GPU -> three BFQRANS2 containers (pinned); the raw streams never cross the bus"}
         log(f"fused steps 1-5: {dt * 1e3:.0f} ms")
         # the same with eBWT-domain containers: rows of the edited eBWT instead of reads (no inversion on the compressing side)
         eng.fastq_job([text], streams=True, hdr=True, fastq=False, out=zb, compress=2)
@@ -227,7 +251,7 @@ def stream_codec(api, eng, outs, lens, N, L, log, with_cpu, text=None):
             v.free()
     res["total"] = {"raw_bytes": int(tot_raw), "compressed_bytes": int(tot_cmp), "ratio": round(tot_raw / max(tot_cmp, 1), 2),
                     "compress_GB_per_s_host_to_host": round(tot_raw / 1e9 / tot_t, 2)}
-    res["what"] = ("OUT.fq.dna / OUT.fq.qs / OUT.h of the e2e_host run -> bfq_stream_compress (BFQRANS1: static order-k model + rANS, "
+    res["what"] = ("OUT.fq.dna / OUT.fq.qs / OUT.h of the e2e_host run -> bfq_stream_compress (BFQRANS2: static order-k model + rANS, "
                    "8192-symbol segments, one lane per segment) -> bfq_stream_decompress; container = oracle/bfq_codec_ref.c byte for byte")
     return res
 
@@ -292,36 +316,109 @@ def global_mode(api, parallel, eng, text, N, L, dna_ref, qs_ref, log):
         shutil.rmtree(d, ignore_errors=True)
 
 
-def dropin_wall(text, N, L, params, log):
-    """`gsufsort in.fastq --bwt --qs -o OUT` then `bfq_int -e OUT.bwt -q OUT.bwt.qs -o OUT.fq -m 5` (BFQzip.py:184,215-222)
-    with the drop-in executables on /dev/shm files; wall seconds per tool (process start, file I/O, PCIe, GPU work)."""
+_GEN = ("import sys; sys.path.insert(0, %r)\n"
+        "from bfqzip_amd import api\n"
+        "N, L, dev, path = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]\n"
+        "e = api.Engine(dev); p = api.PinnedBuffer(N * (2 * L + 30) + 4096)\n"
+        "l = e.synth_fastq(api.synth_spec(N, L, seed=20240807), p.array)\n"
+        "f = open(path, 'wb'); mv = memoryview(p.array[:l])\n"
+        "[f.write(mv[o:o + (1 << 30)]) for o in range(0, l, 1 << 30)]; f.close(); e.close(); p.free(); print(l)\n") % ROOT
+
+
+def _phases(stderr_text):
+    for line in reversed(stderr_text.splitlines()):
+        if line.startswith("[bfq phases] "):
+            try:
+                return json.loads(line[len("[bfq phases] "):])
+            except ValueError:
+                return None
+    return None
+
+
+def dropin_wall(N, L, params, device, log, keep=False):
+    """`gsufsort in.fastq --bwt --qs -o OUT` then `bfq_int -e OUT.bwt -q OUT.bwt.qs -o OUT.fq -m 5` (BFQzip.py:184,215-222) with
+    the drop-in executables on /dev/shm files, one right after the other as BFQzip.py runs them: wall seconds per tool
+    and each tool's own phase split (its `[bfq phases]` line: exec -> main, lease, HIP start, allocations, file read + H2D,
+    GPU, D2H + file write, teardown).  Runs BEFORE this process has created its engine: the input file is written by a
+    child process (GPU generator), and the leg starts `settle_s` seconds after that child has gone, so that no tool waits
+    for the driver to scrub HBM that the bench itself has just freed."""
     gs = os.path.join(ROOT, "dropin", "external", "gsufsort", "gsufsort")
     bi = os.path.join(ROOT, "dropin", "src_int_mem", "bfq_int")
     if not (os.path.exists(gs) and os.path.exists(bi)):
-        return {"skipped": "drop-in executables not built (make -C bfqzip_amd/csrc cli)"}
+        return {"skipped": "drop-in executables not built (make -C bfqzip_amd/csrc cli)"}, None
     d = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    ok_keep = False
     try:
         t0 = time.perf_counter()
-        with open(d + "/in.fastq", "wb") as f:
-            mv = memoryview(text)
-            for o in range(0, len(mv), 1 << 30):
-                f.write(mv[o:o + (1 << 30)])
+        tlen = int(subprocess.check_output([sys.executable, "-c", _GEN, str(N), str(L), str(device), d + "/in.fastq"], timeout=600).split()[-1])
         t1 = time.perf_counter()
-        env = dict(os.environ, BFQ_M=str(params["M"]), BFQ_B=str(params["B"]))
-        subprocess.check_call([gs, d + "/in.fastq", "--bwt", "--qs", "-o", d + "/OUT"], stdout=subprocess.DEVNULL, env=env, timeout=1200)
-        t2 = time.perf_counter()
-        subprocess.check_call([bi, "-e", d + "/OUT.bwt", "-q", d + "/OUT.bwt.qs", "-o", d + "/OUT.fq", "-m", str(params["m"])],
-                              stdout=subprocess.DEVNULL, env=env, timeout=1200)
-        t3 = time.perf_counter()
+        settle = 2.0 if N * L > 10**9 else 0.5
+        time.sleep(settle)
+        env = dict(os.environ, BFQ_M=str(params["M"]), BFQ_B=str(params["B"]), BFQ_TRACE="1", BFQ_DEVICE=str(device))
+        ta = time.perf_counter()
+        r1 = subprocess.run([gs, d + "/in.fastq", "--bwt", "--qs", "-o", d + "/OUT"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=1200, text=True)
+        tb = time.perf_counter()
+        if r1.returncode:
+            return {"error": "gsufsort: " + r1.stderr[-400:]}, None
+        r2 = subprocess.run([bi, "-e", d + "/OUT.bwt", "-q", d + "/OUT.bwt.qs", "-o", d + "/OUT.fq", "-m", str(params["m"])],
+                            stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, env=env, timeout=1200, text=True)
+        tc = time.perf_counter()
+        if r2.returncode:
+            return {"error": "bfq_int: " + r2.stderr[-400:]}, None
         osz = os.path.getsize(d + "/OUT.fq")
         ok = osz == N * (2 * L + 6)                                  # "@" headers: 1 + 1 + L + 1 + 2 + L + 1 per read
-        log(f"dropin {N}x{L}: write {t1 - t0:.2f}s gsufsort {t2 - t1:.2f}s bfq_int {t3 - t2:.2f}s size_ok={ok}")
-        return {"gsufsort": round(t2 - t1, 3), "bfq_int": round(t3 - t2, 3), "total": round(t3 - t1, 3),
-                "Mbases_per_s": round(N * L / 1e6 / (t3 - t1), 1), "fastq_bytes": int(len(text)), "output_size_ok": bool(ok)}
+        log(f"dropin {N}x{L}: generate {t1 - t0:.2f}s gsufsort {tb - ta:.2f}s bfq_int {tc - tb:.2f}s size_ok={ok}")
+        res = {"gsufsort": round(tb - ta, 3), "bfq_int": round(tc - tb, 3), "total": round(tc - ta, 3),
+               "Mbases_per_s": round(N * L / 1e6 / (tc - ta), 1), "fastq_bytes": tlen, "output_size_ok": bool(ok),
+               "phases": {"gsufsort": _phases(r1.stderr), "bfq_int": _phases(r2.stderr)}, "settle_s": settle,
+               "what": "wall seconds of the two processes back to back on /dev/shm files, first GPU work of this bench run "
+                       "(input written by a child process that exited settle_s before); phases = each tool's own timeline"}
+        ok_keep = keep and ok
+        return res, (d if ok_keep else None)
     except Exception as e:
-        return {"error": f"{type(e).__name__}: {e}"}
+        return {"error": f"{type(e).__name__}: {e}"}, None
+    finally:
+        if not ok_keep:
+            shutil.rmtree(d, ignore_errors=True)
+
+
+def dropin_parity(d, N, L, dna, qs):
+    """OUT.fq of the drop-in leg against the streams of the in-process fused call (e2e_host): lines 2 and 4 of every record."""
+    try:
+        rec = 2 * L + 6
+        fq = np.memmap(d + "/OUT.fq", np.uint8, "r")
+        if len(fq) != N * rec:
+            return False
+        same = True
+        step = 1_000_000
+        for a in range(0, N, step):
+            b = min(N, a + step)
+            blk = np.asarray(fq[a * rec:b * rec]).reshape(b - a, rec)
+            same = same and np.array_equal(blk[:, 2:2 + L], dna[a * (L + 1):b * (L + 1)].reshape(b - a, L + 1)[:, :L])
+            same = same and np.array_equal(blk[:, L + 5:2 * L + 5], qs[a * (L + 1):b * (L + 1)].reshape(b - a, L + 1)[:, :L])
+            if not same:
+                break
+        del fq
+        return bool(same)
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def device_state(local):
+    """Clocks / power cap of the GPU as rocm-smi reports them (why one box runs a pass in 27 ms and another in 33)."""
+    try:
+        o = subprocess.run(["rocm-smi", "-d", str(local), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
+                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30, text=True).stdout
+        j = json.loads(o[o.index("{"):])
+        card = next(iter(j.values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(x in kl for x in ("sclk", "mclk", "fclk", "socclk", "power", "performance level")):
+                keep[k] = v
+        return keep
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {e}"}
 
 
 def main():
@@ -363,11 +460,18 @@ def main():
     Nw, L = parse_workload(args.workload)
     B = args.B if args.B is not None else (1 if (Nw, L) == (30_000_000, 150) else 0)   # BASELINE.json configs[2]: B=1
     par = dict(k=16, m=5, v=ord(">"), f=40, t=20, M=args.M, B=B, piles=args.piles)    # -m 5: what BFQzip.py passes
-    eng = api.Engine(local, **par)
 
     def log(msg):
         if rank == 0:
             print(f"[bench +{time.perf_counter() - tstart:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    # the drop-in tools first, before this process holds any HBM (see dropin_wall)
+    dropin_res, dropin_dir = {}, None
+    if world == 1 and not args.no_dropin:
+        dropin_res[f"{Nw}x{L}"], dropin_dir = dropin_wall(Nw, L, par, local, log, keep=not args.no_e2e)
+        if (Nw, L) != (1_000_000, 100):
+            dropin_res["1000000x100"], _ = dropin_wall(1_000_000, 100, dict(par, B=0), local, log)
+    eng = api.Engine(local, **par)
 
     def barrier():
         if world > 1:
@@ -401,11 +505,15 @@ def main():
         for i in range(warmup):
             st = step()
             log(f"[{scaling}] warmup step {i} done, workspace {eng.workspace_bytes() / 2**30:.1f} GiB")
+        eng.prof_trace_select("k_radix_scatter")
         eng.prof_reset()
+        step_ms = []
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
+            ts = time.perf_counter()
             st = step()
+            step_ms.append((time.perf_counter() - ts) * 1e3)      # the call returns synchronised (it reads the counters back)
             if world > 1:                                   # the only exchange: per-block output sizes (one integer per rank)
                 sz = torch.tensor([sum(b[1] for b in bufs)], dtype=torch.int64, device=cdev)
                 lst = [torch.empty_like(sz) for _ in range(world)]
@@ -421,12 +529,16 @@ def main():
         else:
             bases_all = float(bases)
         prof = eng.prof()
+        prof["_step_ms"] = step_ms
+        prof["_scatter_ms"] = [float(x) for x in eng.prof_trace()]
+        eng.prof_trace_select(None)
         reads = sum(b[0] for b in bufs)
         del bufs
         torch.cuda.empty_cache()
         return dt, bases_all, prof, st, reads
 
     dt, bases_all, prof, st, reads_rank = measure(args.scaling, args.steps, args.warmup)
+    step_ms, scatter_ms = prof.pop("_step_ms"), prof.pop("_scatter_ms")
     log(f"{args.steps} timed steps ({args.scaling}): {dt:.3f}s")
     strong_extra = None
     if world > 1 and args.scaling == "weak":                # configs[3] beside the weak figure
@@ -453,6 +565,30 @@ def main():
                 "job_frac": round(alg_bytes_per_base(L) * (bases_all / world / (dt / args.steps)) / (HBM_PEAK_GBS * 1e9), 4)}
         kern = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         # the same figure for the other heavy kernels (algorithmic GB/s and fraction of the HBM peak)
+        # the sort passes one by one (launch order: KEY_PASSES scatters per step; pass 0 reads the records k_build_keys wrote)
+        if scatter_ms and len(scatter_ms) % args.steps == 0:
+            pp = len(scatter_ms) // args.steps
+            a = np.asarray(scatter_ms, np.float64).reshape(args.steps, pp)
+            roof["scatter_passes_ms"] = {"per_step": pp, "median": [round(float(x), 3) for x in np.median(a, axis=0)],
+                                         "min": [round(float(x), 3) for x in a.min(axis=0)], "max": [round(float(x), 3) for x in a.max(axis=0)]}
+        # Three ways to price the whole job against the 8 TB/s peak, side by side:
+        #   job_frac       SURVEY 8(d)'s A(L) (an 8-pass sort of 16-byte records, a 64-byte rank block per LF step)
+        #   job_frac_impl  the bytes THIS implementation must move: the kernels' own algorithmic bytes (5 passes of 12-byte
+        #                  records ...), the LF walk priced at the 8-byte table entry + 2 bytes written per base it really needs
+        #   job_frac_pmc   the HBM traffic rocprofv3's FETCH_SIZE / WRITE_SIZE counters measured (profiles/*/traffic_per_row.json)
+        inv = prof.get("k_invert", {"alg_bytes": 0.0})
+        bases_rank = reads_rank * L
+        impl_bytes = (sum(v["alg_bytes"] for v in prof.values()) - inv["alg_bytes"]) / args.steps + 10.0 * bases_rank
+        rate_rows = rows_rank / (dt / args.steps)
+        roof["impl_alg_bytes_per_row"] = round(impl_bytes / max(rows_rank, 1), 1)
+        roof["job_frac_impl"] = round(impl_bytes / max(rows_rank, 1) * rate_rows / (HBM_PEAK_GBS * 1e9), 4)
+        tpr = pmc_traffic_per_row()
+        if tpr and (Nw, L) == (30_000_000, 150):
+            roof["pmc_bytes_per_row"] = round(tpr, 1)
+            roof["job_frac_pmc"] = round(tpr * rate_rows / (HBM_PEAK_GBS * 1e9), 4)
+        roof["k_invert_need"] = {"alg_bytes_per_base_survey": 68.0, "alg_bytes_per_base_impl": 10.0,
+                                 "frac_impl": round(10.0 * bases_rank / (inv["ms"] / max(inv.get("launches", 1), 1) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if inv.get("ms") else None,
+                                 "what": "SURVEY prices an LF step at a 64-byte rank block; the tabulated LF entry is 8 bytes (+ 2 written): a random 8-byte read still fetches a 64-byte sector"}
         roof["by_kernel"] = {k: {"avg_launch_ms": round(v["ms"] / v["launches"], 3),
                                  "achieved": round(v["alg_bytes"] / v["launches"] / (v["ms"] / v["launches"] * 1e-3) / 1e9, 1),
                                  "frac": round(v["alg_bytes"] / v["launches"] / (v["ms"] / v["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -466,7 +602,9 @@ def main():
                           "read_len": L, "rows_rank0": rows_rank, "parallelism": f"{world} independent blocks"},
                "roofline": roof, "kernel_ms_per_step": kern,
                "stats": {k: st[k] for k in ("num_clust", "bases_inside", "qs_smoothed", "modified", "n_segments", "n_big_segments")},
-               "workspace_gib": round(eng.workspace_bytes() / 2**30, 2)}
+               "workspace_gib": round(eng.workspace_bytes() / 2**30, 2),
+               "step_ms": {"min": round(min(step_ms), 3), "median": round(float(np.median(step_ms)), 3), "max": round(max(step_ms), 3)},
+               "device_state": device_state(local)}
         if strong_extra:
             res["strong"] = strong_extra
         if world == 1:
@@ -476,6 +614,9 @@ def main():
                     sp = api.synth_spec(Nw, L, seed=20240807)
                     res["e2e_host"], pin, tlen, outs = e2e_host(api, eng, sp, Nw, L, 3, log)
                     text = pin.array[:tlen]
+                    if dropin_dir is not None:                  # parity of the drop-in leg's OUT.fq, checked while the streams exist
+                        dropin_res[f"{Nw}x{L}"]["fastq_equals_fused_streams"] = dropin_parity(dropin_dir, Nw, L, outs["dna"].array, outs["qs"].array)
+                        dropin_dir = None
                 except Exception as e:                       # e.g. pinned memory refused: reported, not fatal
                     res["e2e_host"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_e2e and text is not None and "error" not in res.get("e2e_host", {}):
@@ -504,22 +645,10 @@ def main():
                 if not res["sample_parity"]:
                     rc = 3
                     res["value"] = None                      # a number whose output differs from the reference's is not a result
-            if not args.no_dropin:
-                eng.close()                                  # the tools create their own contexts: give the HBM back first
-                torch.cuda.empty_cache()
-                dw = {}
-                if text is not None:
-                    dw[f"{Nw}x{L}"] = dropin_wall(text, Nw, L, par, log)
-                if (Nw, L) != (1_000_000, 100):
-                    try:
-                        e1 = api.Engine(local, **par)
-                        p1 = api.PinnedBuffer(1_000_000 * 230 + 4096)
-                        l1 = e1.synth_fastq(api.synth_spec(1_000_000, 100, seed=20240807), p1.array)
-                        e1.close()
-                        dw["1000000x100"] = dropin_wall(p1.array[:l1], 1_000_000, 100, dict(par, B=0), log)
-                    except Exception as e:
-                        dw["1000000x100"] = {"error": f"{type(e).__name__}: {e}"}
-                res["dropin_wall_s"] = dw
+            if dropin_dir is not None:
+                shutil.rmtree(dropin_dir, ignore_errors=True)
+            if dropin_res:
+                res["dropin_wall_s"] = dropin_res
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -14,14 +14,14 @@ _LIB = None
 SYMBOLS = [
     "bfq_default_params", "bfq_create", "bfq_create_error", "bfq_destroy", "bfq_set_params",
     "bfq_last_error", "bfq_stream", "bfq_device_count", "bfq_pick_device", "bfq_device_lease", "bfq_device_release",
-    "bfq_phase_enable", "bfq_phase", "bfq_phase_report", "bfq_build_ebwt", "bfq_count_reads",
+    "bfq_phase_enable", "bfq_phase", "bfq_phase_report", "bfq_output_prefault", "bfq_fastq_rows_estimate", "bfq_build_ebwt", "bfq_count_reads",
     "bfq_smooth_invert", "bfq_run_reads", "bfq_run_reads_device", "bfq_fetch_ebwt",
     "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_fastq_run_streams",
     "bfq_smooth_invert_fastq", "bfq_fastq_run_job", "bfq_host_alloc", "bfq_host_free",
     "bfq_text_count_lines", "bfq_text_nth_newline", "bfq_fastq_build_ebwt_fd", "bfq_smooth_invert_fastq_fd",
     "bfq_glob_begin", "bfq_glob_local_text", "bfq_glob_pile_counts", "bfq_glob_init_out", "bfq_glob_run_pile", "bfq_glob_finish",
     "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device", "bfq_synth_fastq",
-    "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get",
+    "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get", "bfq_prof_trace_select", "bfq_prof_trace",
     "bfq_stream_bound", "bfq_stream_raw_len", "bfq_stream_compress", "bfq_stream_decompress",
     "bfq_stream_reserve", "bfq_stream_compress_device", "bfq_stream_ebwt_decode",
     "bfq_workspace_bytes", "bfq_version",
@@ -111,6 +111,9 @@ def lib():
         L.bfq_phase_enable.argtypes = [C.c_int]
         L.bfq_phase.argtypes = [C.c_char_p]
         L.bfq_phase_report.argtypes = [C.c_char_p]
+        L.bfq_output_prefault.argtypes = [C.c_int, u64, u64]
+        L.bfq_fastq_rows_estimate.restype = u64
+        L.bfq_fastq_rows_estimate.argtypes = [C.c_int, u64]
         L.bfq_build_ebwt.argtypes = [vp, vp, vp, vp, u64, C.c_int, vp, vp, vp]
         L.bfq_count_reads.argtypes = [vp, u64, C.c_int, C.POINTER(u64)]
         L.bfq_smooth_invert.argtypes = [vp, vp, vp, vp, C.c_int, u64, vp, vp, vp, C.POINTER(Stats)]
@@ -155,6 +158,9 @@ def lib():
         L.bfq_prof_enable.argtypes = [vp, C.c_int]
         L.bfq_prof_reset.argtypes = [vp]
         L.bfq_prof_count.argtypes = [vp]
+        L.bfq_prof_trace_select.argtypes = [vp, C.c_int]
+        L.bfq_prof_trace.restype = C.c_int64
+        L.bfq_prof_trace.argtypes = [vp, vp, u64]
         L.bfq_prof_get.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_double),
                                    C.POINTER(u64), C.POINTER(C.c_double)]
         _LIB = L

@@ -213,7 +213,7 @@ class Engine:
         """One block of BFQzip_parallel.py in one call (bfq_fastq_run_job): `parts` = 1..4 byte ranges (bytes,
         uint8 arrays, memmap slices) processed as one collection; outputs as asked: the FASTQ text, the --m2
         streams (dna, qs), the --m3 header stream.  `out` may give reusable output arrays (e.g. PinnedBuffer.array)
-        under the keys 'fastq', 'dna', 'qs', 'hdr'.  compress=True: the streams come back as BFQRANS1 containers
+        under the keys 'fastq', 'dna', 'qs', 'hdr'.  compress=True: the streams come back as BFQRANS2 containers
         (steps 1-5 of the reference in one call; stream_decompress gives the raw stream)."""
         arrs = [_u8(p) for p in parts]
         np_ = len(arrs)
@@ -352,7 +352,7 @@ class Engine:
 
     # ---- stream codec (step 5 of the reference: BFQzip.py:253-275)
     def stream_compress(self, data, out=None):
-        """BFQRANS1 container of the bytes `data` (uint8 array); returns a uint8 array (a view of `out` when given)."""
+        """BFQRANS2 container of the bytes `data` (uint8 array); returns a uint8 array (a view of `out` when given)."""
         data = _u8(data)
         cap = int(self.L.bfq_stream_bound(len(data)))
         if out is None:
@@ -362,11 +362,11 @@ class Engine:
         return out[:int(ol.value)]
 
     def stream_decompress(self, blob, out=None):
-        """The raw bytes of a BFQRANS1 container."""
+        """The raw bytes of a BFQRANS2 container."""
         blob = _u8(blob)
         n = int(self.L.bfq_stream_raw_len(_ptr(blob), len(blob)))
         if n < 0:
-            raise BfqError(-1, "not a BFQRANS1 stream")
+            raise BfqError(-1, "not a BFQRANS2 stream")
         if out is None:
             out = np.empty(max(n, 1), np.uint8)
         ol = C.c_uint64(0)
@@ -409,6 +409,26 @@ class Engine:
             self.L.bfq_prof_get(self.h, i, name, 64, C.byref(ms), C.byref(ln), C.byref(by))
             if ln.value:
                 out[name.value.decode()] = {"ms": ms.value, "launches": ln.value, "alg_bytes": by.value}
+        return out
+
+    def prof_trace_select(self, kernel):
+        """Keep the per-launch durations of `kernel` (a name prof() reports, or None) from now on."""
+        name = C.create_string_buffer(64)
+        idx = -1
+        for i in range(self.L.bfq_prof_count(self.h)):
+            self.L.bfq_prof_get(self.h, i, name, 64, None, None, None)
+            if kernel is not None and name.value.decode() == kernel:
+                idx = i
+        if kernel is not None and idx < 0:
+            raise KeyError(kernel)
+        self._ck(self.L.bfq_prof_trace_select(self.h, idx))
+
+    def prof_trace(self):
+        """Per-launch milliseconds of the selected kernel since the last prof_reset(), launch order (float32 array)."""
+        k = int(self.L.bfq_prof_trace(self.h, None, 0))
+        out = np.empty(max(k, 0), np.float32)
+        if k > 0:
+            self.L.bfq_prof_trace(self.h, _ptr(out), k)
         return out
 
     def workspace_bytes(self):

@@ -34,8 +34,12 @@ void bfq_ctx::reserve(size_t bytes)
         if (ws) { HIP_CHECK(hipStreamSynchronize(stream)); HIP_CHECK(hipFree(ws)); ws = nullptr; wsCap = 0; }
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
-        hipError_t e = hipMalloc((void **)&ws, bytes);
+        hipError_t e = hipErrorOutOfMemory;
+        bool contig = false;
+        if (env.wsContig) { e = hipExtMallocWithFlags((void **)&ws, bytes, hipDeviceMallocContiguous); contig = e == hipSuccess; if (!contig) (void)hipGetLastError(); }
+        if (e != hipSuccess) e = hipMalloc((void **)&ws, bytes);
         clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (bfq_env().trace && env.wsContig) fprintf(stderr, "[bfq] workspace: contiguous allocation %s\n", contig ? "granted" : "refused");
         if (bfq_env().trace) fprintf(stderr, "[bfq] workspace %.1f GiB: hipMalloc %.3f s\n", bytes / 1073741824.0, (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec));
         if (e != hipSuccess) {
             ws = nullptr;
@@ -90,6 +94,7 @@ void bfq_ctx::profCollect()
         float ms = 0;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
             profMs[r.id] += ms; profLaunches[r.id]++; profBytes[r.id] += r.bytes;
+            if (r.id == profTraceId && profTrace.size() < (1u << 20)) profTrace.push_back(ms);
         }
     }
     recs.clear();
@@ -231,6 +236,22 @@ extern "C" void bfq_prof_reset(bfq_ctx *c)
     if (!c) return;
     memset(c->profMs, 0, sizeof c->profMs); memset(c->profLaunches, 0, sizeof c->profLaunches);
     memset(c->profBytes, 0, sizeof c->profBytes);
+    c->profTrace.clear();
+}
+// per-launch durations of ONE kernel (by its bfq_prof_get index; -1: none) in launch order since the last bfq_prof_reset():
+// bfq_prof_trace_select() chooses it, bfq_prof_trace() copies up to cap values and returns how many there are
+extern "C" int bfq_prof_trace_select(bfq_ctx *c, int idx)
+{
+    if (!c || idx < -1 || idx >= K_NUM) return BFQ_E_ARG;
+    c->profTraceId = idx; c->profTrace.clear();
+    return BFQ_OK;
+}
+extern "C" int64_t bfq_prof_trace(bfq_ctx *c, float *ms, uint64_t cap)
+{
+    if (!c) return BFQ_E_ARG;
+    const size_t k = std::min<size_t>(cap, c->profTrace.size());
+    if (ms && k) memcpy(ms, c->profTrace.data(), k * sizeof(float));
+    return (int64_t)c->profTrace.size();
 }
 extern "C" int bfq_prof_count(bfq_ctx *c) { (void)c; return K_NUM; }
 extern "C" int bfq_prof_get(bfq_ctx *c, int idx, char *name, int cap, double *ms, uint64_t *launches, double *bytes)
@@ -319,7 +340,7 @@ static void reserve_step1(bfq_ctx *c, u64 n, u64 N, u64 extra)
     const u64 cap = n / 10 * 3 + (1u << 20);                     // a DNA pile holds about a quarter of the suffixes; larger ones are split again
     c->piles = false;
     if (mode <= 0) {
-        try { c->reserve(ws_need(n, N, extra)); return; }
+        try { c->reserve(ws_need(n, N, extra + c->env.abPad + (c->env.abSwap ? 12 * (n + 256) : 0))); return; }
         catch (const BfqError &e) { if (mode < 0 || e.code != BFQ_E_NOMEM) throw; }
     }
     c->reserve(bfq_ws_need_piles(n, N, cap, extra));
@@ -344,11 +365,15 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
     u64 *text3 = c->alloc<u64>(nwords);
     SortRec A, B;
+    const bool abSwap = c->env.abSwap && !c->keepRecs;  // placement experiment: B below A
+    if (abSwap) { B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16); }
     A.w12 = c->alloc<u64>(n + 16);
     const size_t mKeep = c->mark();                     // position mode keeps the text and the records' (w1, w2) words
     A.w0 = c->alloc<u32>(n + 16);
     size_t mB = c->mark();
-    B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16);
+    if (c->env.abPad) (void)c->allocBytes((size_t)c->env.abPad);
+    if (!abSwap) { B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16); }
+    if (bfq_env().trace) fprintf(stderr, "[bfq] sort buffers: A.w12 %p A.w0 %p B.w0 %p B.w12 %p (arena %p)\n", (void *)A.w12, (void *)A.w0, (void *)B.w0, (void *)B.w12, (void *)c->ws);
     u8 *T8 = (u8 *)A.w0, *Q8 = (u8 *)A.w12;             // dead before the sort's first scatter
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
     u32 *hist0 = c->alloc<u32>(256 * ceil_div(n, bfq_radix_block_elems(n)));
@@ -801,8 +826,21 @@ static void fastq_build_ebwt_core(bfq_ctx *c, TextSrc text, int term_out, HostRe
 struct OutFile {
     int fd = -1;
     bfq_outmap *m = nullptr;
-    HostRef at(u64 off) const { return m ? HostRef::mem(bfq_outmap_ptr(m) + off) : HostRef::file(fd, off); }
-    void open(int f, u64 mapLen, u64 prefault) { fd = f; if (f >= 0) m = bfq_outmap_open(f, mapLen, prefault); }
+    HostRef at(u64 off) const
+    {
+        if (!m) return HostRef::file(fd, off);
+        HostRef h = HostRef::mem(bfq_outmap_ptr(m) + off);
+        h.om = m; h.off = off;
+        return h;
+    }
+    void open(int f, u64 mapLen, u64 prefault)
+    {
+        fd = f;
+        if (f < 0) return;
+        m = bfq_outmap_take(f, mapLen);
+        if (m) bfq_outmap_extend(m, prefault);
+        else m = bfq_outmap_open(f, mapLen, prefault);
+    }
     bool close(u64 finalLen)
     {
         bool ok = true;
@@ -812,74 +850,73 @@ struct OutFile {
         return ok;
     }
 };
-// eBWT rows per byte of a FASTQ file, from the complete records among its first bytes (sizes the background pre-fault of
-// the outputs before the file has been parsed; a wrong guess costs time, never correctness)
-static double sample_rows_per_byte(const TextSrc &t)
-{
-    const size_t want = (size_t)std::min<u64>(t.len, 1u << 20);
-    if (!want) return 0;
-    std::vector<u8> b(want);
-    if (t.ref.ptr) memcpy(b.data(), t.ref.ptr, want);
-    else if (pread(t.ref.fd, b.data(), want, (off_t)t.ref.off) != (ssize_t)want) return 0.45;
-    u64 rows = 0, used = 0;
-    size_t pos = 0;
-    for (;;) {
-        size_t e[4], p = pos;
-        int k = 0;
-        for (; k < 4; k++) {
-            const void *q = p < want ? memchr(b.data() + p, '\n', want - p) : nullptr;
-            if (!q) break;
-            e[k] = (size_t)((const u8 *)q - b.data());
-            p = e[k] + 1;
-        }
-        if (k < 4) break;
-        size_t L = e[1] - (e[0] + 1);
-        if (L && b[e[1] - 1] == '\r') L--;
-        rows += L + 1;
-        used = p;
-        pos = p;
-    }
-    return used ? (double)rows / (double)used : 0.45;
-}
-
 static void fastq_build_ebwt_oneshot(bfq_ctx *c, int fastq_fd, uint64_t len, int term_out, int bwt_fd, int qs_fd, int lcp_fd, int lcp_bytes,
                                      uint64_t *n_rows, uint64_t *n_reads)
 {
     const bool wantLcp = lcp_fd >= 0;
     if (wantLcp && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
     TextSrc text{HostRef::file(fastq_fd), len};
-    // the outputs are sized to their bound (rows <= bytes / 2) and pre-faulted from the first moment on: by the time the
-    // first pile is sorted the page cache pages exist and the copy out of the staging buffers runs at memcpy speed
-    const u64 capRows = len / 2 + 64, est = (u64)(sample_rows_per_byte(text) * (double)len * 0.98);
+    // The outputs are sized to their bound (rows <= bytes / 2) and pre-faulted in the background -- from the moment the tool
+    // opened them (bfq_output_prefault) or from here: by the time the first pile is sorted the page-cache pages exist and the
+    // copy out of the staging buffers runs at memcpy speed.
+    const u64 capRows = len / 2 + 64, est = bfq_fastq_rows_estimate(fastq_fd, len);
     OutFile ob, oq, ol;
     ob.open(bwt_fd, capRows, est);
     oq.open(qs_fd, capRows, est);
     if (wantLcp) ol.open(lcp_fd, capRows * (u64)lcp_bytes, est * (u64)lcp_bytes);
     u64 n = 0;
     bool done = false;
+    // HBM of this process, and why it is cut into pieces: the driver scrubs freed HBM at ~30 GB/s and the NEXT process's
+    // allocations wait for it (profiles/microbench/alloc_after_exit.hip; profiles/r3/dropin_phases.md: bfq_int waited 1.3-4.3 s
+    // behind a gsufsort that had held 102 GiB).  So every piece is as small as its contents and goes back the moment it is dead:
+    //   text buffer   the FASTQ text, then (the reads gathered) the eBWT and its qualities until they are written
+    //   parse arena   line index, records, gathered reads: freed once the terminated text is built
+    //   text arrays   T8 / Q8 / packed text: until the last pile is sorted
+    //   arena         sort records + histograms of ONE pile, sized from the actual pile sizes
+    char *pws = nullptr, *tws = nullptr;
+    char *const ws0 = c->ws; const size_t cap0 = c->wsCap;
+    bool swapped = false;
+    auto restoreArena = [&] { if (swapped) { c->ws = ws0; c->wsCap = cap0; c->wsTop = 0; swapped = false; } };
     auto finish = [&](bool ok) {
-        c->onRows = nullptr; c->extBwt = c->extQual = nullptr;
+        c->onRows = nullptr; c->extBwt = c->extQual = nullptr; c->lcpScratch = false;
         if (!ok) { try { bfq_write_wait(c); } catch (...) {} }
+        (void)hipStreamSynchronize(c->stream);
+        restoreArena();
+        if (pws) { (void)hipFree(pws); pws = nullptr; }
+        if (tws) { (void)hipFree(tws); tws = nullptr; }
         const bool a = ob.close(ok ? n : 0), b = oq.close(ok ? n : 0), l = ol.close(ok ? n * (u64)lcp_bytes : 0);
         if (ok && !(a && b && l)) throw BfqError{BFQ_E_IO, "cannot size the output files"};
     };
     try {
-        std::vector<u64> ps;
-        u8 *d_fq = fastq_upload_and_reserve(c, &text, 1, ps, wantLcp ? (size_t)lcp_bytes * (len / 2 + 4096) : 0);
+        bfq_phase("alloc");
+        const bool addNl = !src_ends_with_newline(text);
+        const u64 tl = len + (addNl ? 1 : 0);
+        u8 *d_fq = c->textBuf(tl + 64);
+        bfq_phase("read_h2d");
+        bfq_upload(c, d_fq, text.ref, len);
+        if (addNl) HIP_CHECK(hipMemsetAsync(d_fq + len, '\n', 1, c->stream));
+        bfq_phase("alloc");
+        c->reserve(16 * (tl / 4096 + 16) + (64u << 20));
+        bfq_phase("gpu");
+        const u64 nlines = bfq_fastq_count_lines(c, d_fq, tl);
+        const u64 Nb = nlines / 4 + 1;
+        bfq_phase("alloc");
+        const size_t parseBytes = (tl + 8192) + 128 * (Nb + 64) + 8 * (nlines + 64) + 16 * (tl / 4096 + 16) + (64u << 20);
+        if (hipMalloc((void **)&pws, parseBytes) != hipSuccess) { (void)hipGetLastError(); pws = nullptr; throw BfqError{BFQ_E_NOMEM, "device buffer for the parsed records"}; }
+        c->ws = pws; c->wsCap = parseBytes; c->wsTop = 0; swapped = true;      // ws0 (the small arena) comes back below
+        bfq_phase("gpu");
         c->zeroCounters();
         DevFastq fq;
-        bfq_fastq_parse(c, d_fq, ps[1], &fq);
+        bfq_fastq_parse(c, d_fq, tl, &fq);
         n = fq.total + fq.N;
+        const u64 N = fq.N;
         if (n_rows) *n_rows = n;
-        if (n_reads) *n_reads = fq.N;
-        // The reads are gathered: the FASTQ text is dead and its buffer takes the eBWT and the qualities.  They then outlive
-        // the arena, which is freed as soon as the last pile is emitted: the driver scrubs freed HBM at ~28 GB/s and the NEXT
-        // process's first allocation waits for it (profiles/microbench/alloc_after_exit.hip), so the scrubbing should run
-        // while this process is still writing, not while bfq_int is starting.
+        if (n_reads) *n_reads = N;
+        c->writeHint = (size_t)n * (2 + (wantLcp ? (size_t)lcp_bytes : 0));
         const u64 npad = (n + 64 + 255) & ~255ull;
-        if (2 * npad <= c->textCap) { c->extBwt = c->d_text; c->extQual = c->d_text + npad; }
-        u8 *raw = (wantLcp && lcp_bytes != 2) ? c->alloc<u8>((size_t)lcp_bytes * n + 64) : nullptr;
-        c->onRows = [&](u64 start, u64 m) {                     // rows [start, start + m) are final: out they go, while the next pile is sorted
+        const bool ext = 2 * npad <= c->textCap;                // always (rows <= bytes / 2); the FASTQ text is dead from here on
+        u8 *raw = nullptr;
+        auto hook = [&](u64 start, u64 m) {                     // rows [start, start + m) are final: out they go while the next pile is sorted
             if (!m) return;
             if (ob.fd >= 0) bfq_write_async(c, ob.at(start), c->d_bwt + start, m);
             if (oq.fd >= 0) bfq_write_async(c, oq.at(start), c->d_qual + start, m);
@@ -892,13 +929,63 @@ static void fastq_build_ebwt_oneshot(bfq_ctx *c, int fastq_fd, uint64_t len, int
                 }
             }
         };
-        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, term_out, nullptr);
+        const size_t lcpExtra = wantLcp ? (size_t)(lcp_bytes == 2 ? 0 : lcp_bytes) * (n + 256) + 4096 : 0;
+        if (n < (32u << 20)) {
+            // a small collection: one piece in one arena (0.9 GB at most); the parsed reads stay where they are meanwhile
+            restoreArena();
+            bfq_phase("alloc");
+            c->reserve(ws_need(n, N, lcpExtra));
+            bfq_phase("gpu");
+            c->piles = false;
+            if (ext) { c->extBwt = c->d_text; c->extQual = c->d_text + npad; }
+            if (wantLcp && lcp_bytes != 2) raw = c->alloc<u8>((size_t)lcp_bytes * n + 64);
+            c->onRows = hook;
+            bfq_step1_device(c, fq.bases, fq.quals, fq.roff, N, fq.total, term_out, nullptr);
+        } else {
+            const u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
+            const size_t w3 = (8 * nwords + 255) & ~(size_t)255;
+            bfq_phase("alloc");
+            if (hipMalloc((void **)&tws, 2 * npad + w3 + 8 * (N + 2) + 4096) != hipSuccess) { (void)hipGetLastError(); tws = nullptr; throw BfqError{BFQ_E_NOMEM, "device buffer for the text arrays"}; }
+            bfq_phase("gpu");
+            PileText pt{(u8 *)tws, (u8 *)tws + npad, (u64 *)(tws + 2 * npad)};
+            u64 *roff2 = (u64 *)(tws + 2 * npad + w3);
+            bfq_build_text(c, fq.bases, fq.quals, fq.roff, N, n, pt.T8, pt.Q8, pt.text3, nwords);
+            HIP_CHECK(hipMemcpyAsync(roff2, fq.roff, 8 * (N + 1), hipMemcpyDeviceToDevice, c->stream));
+            u64 cnt[36];
+            bfq_pile_pair_counts(c, pt.T8, n, cnt);             // synchronises
+            c->fetchCounters();
+            check_counters(c);                                  // forbidden symbols, reads beyond BFQ_MAX_READ_LEN
+            restoreArena();
+            (void)hipFree(pws); pws = nullptr;                  // the parsed reads are dead
+            // piles above an eighth of the rows are split by their second symbol; the arena holds the largest piece
+            const u64 capTarget = n / 8 + (1u << 20);
+            u64 cap = 1u << 20;
+            for (int s1 = 1; s1 <= 5; s1++) {
+                u64 tot = 0, big = 0;
+                for (int s2 = 0; s2 <= 5; s2++) { tot += cnt[6 * s1 + s2]; big = std::max(big, cnt[6 * s1 + s2]); }
+                cap = std::max(cap, tot <= capTarget ? tot : big);
+            }
+            bfq_phase("alloc");
+            c->reserve(bfq_ws_need_piles(n, N, cap, lcpExtra + (wantLcp ? 2 * (n + 256) : 0), true));
+            bfq_phase("gpu");
+            c->piles = true;
+            c->lcpScratch = !wantLcp;
+            if (ext) { c->extBwt = c->d_text; c->extQual = c->d_text + npad; }
+            else { c->extBwt = nullptr; c->extQual = nullptr; }
+            if (wantLcp && lcp_bytes != 2) raw = c->alloc<u8>((size_t)lcp_bytes * n + 64);
+            c->onRows = hook;
+            bfq_step1_piles(c, nullptr, nullptr, roff2, N, fq.total, term_out, nullptr, &pt, capTarget);
+        }
         c->onRows = nullptr;
         c->fetchCounters();                                     // waits for the stream
         c->profCollect();
         check_counters(c);
         bfq_phase("d2h_write");
-        if (c->extBwt && !wantLcp) c->dropWorkspace();
+        if (ext && !wantLcp) {                                  // what is still being written lives in the text buffer: the rest goes back now
+            c->dropWorkspace();
+            if (tws) { (void)hipFree(tws); tws = nullptr; }
+            if (pws) { (void)hipFree(pws); pws = nullptr; }
+        }
         bfq_write_wait(c);
         done = true;
     } catch (...) {

@@ -11,12 +11,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sched.h>
 #include <sys/file.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
+#include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -63,6 +66,9 @@ BfqEnv bfq_env_read()
         if (const char *d = getenv("BFQ_LEASE_DIR")) e.leaseDir = d;
         e.invertNt = geti("BFQ_INVERT_NT", 1);
         e.noOutmap = getenv("BFQ_NO_OUTMAP") != nullptr;
+        e.wsContig = geti("BFQ_WS_CONTIG", 0) != 0;
+        e.abPad = getu("BFQ_AB_PAD", 0);
+        e.abSwap = geti("BFQ_AB_SWAP", 0) != 0;
         return e;
     }
 }
@@ -70,6 +76,36 @@ const BfqEnv &bfq_env()
 {
     static const BfqEnv E = bfq_env_read();
     return E;
+}
+
+// CPUs this process may keep busy: the cgroup's quota (cpu.max) when there is one -- a GPU box hands a 256-thread host out in
+// shares of 16 CPUs, and a process that runs more threads than its quota is throttled as a whole, the thread that feeds
+// the GPU included -- else the affinity mask / hardware concurrency.
+int bfq_cpu_budget()
+{
+    static const int budget = [] {
+        int n = (int)std::thread::hardware_concurrency();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0 && (n <= 0 || k < n)) n = k; }
+        for (const char *path : {"/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"}) {
+            FILE *f = fopen(path, "r");
+            if (!f) continue;
+            char a[64] = {0}, b[64] = {0};
+            const int got = fscanf(f, "%63s %63s", a, b);
+            fclose(f);
+            if (got >= 1 && strcmp(a, "max") != 0) {
+                double quota = atof(a), period = got >= 2 ? atof(b) : 100000.0;
+                if (got < 2) {                                   // cgroup v1: the period lives in its own file
+                    FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+                    if (g) { if (fscanf(g, "%lf", &period) != 1) period = 100000.0; fclose(g); }
+                }
+                if (quota > 0 && period > 0) { const int k = (int)(quota / period + 0.5); if (k >= 1 && (n <= 0 || k < n)) n = k; }
+            }
+            break;
+        }
+        return n > 0 ? n : 1;
+    }();
+    return budget;
 }
 
 // ---------------------------------------------------------------- device lease
@@ -229,36 +265,89 @@ extern "C" void bfq_phase_report(const char *tool)
 }
 
 // ---------------------------------------------------------------- output mapping + background pre-fault
+// Measured on the GPU boxes (profiles/microbench/tmpfs_fill.cpp, 8.6 GB on /dev/shm): MADV_POPULATE_WRITE of a new file runs
+// at 6.5 GB/s with 4 threads and SLOWER with more (4.0 GB/s with 8, 3.7 with 16: they contend inside the kernel); a memcpy
+// that takes the faults itself is no faster.  fallocate() allocates and zeroes the same pages at 19 GB/s from ONE thread
+// (no page-table work), MADV_POPULATE_WRITE of pages that exist already then maps them at 43 GB/s, and a memcpy into
+// populated pages runs at 100+ GB/s.  So: few helper threads go through the file slice by slice -- fallocate, then
+// populate -- and whoever wants to copy into a slice waits until it is done instead of faulting beside them (a writer
+// prepares a slice itself only when no helper will).
 struct bfq_outmap {
     int fd = -1;
     char *map = nullptr;
     uint64_t mapLen = 0;
     std::vector<std::thread> th;
-    std::atomic<uint64_t> next{0};
+    std::atomic<uint64_t> next{0};                               // next slice index a helper takes
     std::atomic<bool> stop{false};
+    std::atomic<int> alive{0};
     std::atomic<uint64_t> preEnd{0};
-    double t0 = 0;
     std::atomic<uint64_t> done{0};
+    uint64_t nslices = 0;
+    std::atomic<bool> noFallocate{false};
+    double tOpen = 0, tHelpersDone = 0;
+    std::atomic<uint8_t> *state = nullptr;                       // per slice: 0 untouched, 1 being populated, 2 populated
 };
 static const uint64_t PF_SLICE = 32ull << 20;
 
+// at most this many threads of the process populate at a time, whatever the number of mappings (more are slower in total)
+namespace {
+std::mutex g_popMu;
+std::condition_variable g_popCv;
+int g_popBusy = 0;
+struct PopSlot {
+    PopSlot()
+    {
+        int lim = bfq_env().prefaultThreads;
+        if (lim <= 0) lim = 2;                                   // fallocate + populate of present pages: 2 threads do > 10 GB/s
+        std::unique_lock<std::mutex> lk(g_popMu);
+        g_popCv.wait(lk, [&] { return g_popBusy < lim; });
+        g_popBusy++;
+    }
+    ~PopSlot() { std::lock_guard<std::mutex> g(g_popMu); g_popBusy--; g_popCv.notify_one(); }
+};
+}   // namespace
+static void populate_slice(bfq_outmap *m, uint64_t idx)
+{
+    PopSlot slot;
+    const uint64_t b = idx * PF_SLICE, e = std::min<uint64_t>(b + PF_SLICE, m->mapLen);
+    bool ok = false;
+    if (!m->noFallocate && fallocate(m->fd, 0, (off_t)b, (off_t)(e - b)) != 0) m->noFallocate = true;   // not every file system can
+#ifdef MADV_POPULATE_WRITE
+    ok = madvise(m->map + b, (size_t)(e - b), MADV_POPULATE_WRITE) == 0;
+#endif
+    if (!ok) {                                                   // older kernels: touch every page (the file is new: all zero)
+        const long pg = sysconf(_SC_PAGESIZE);
+        for (uint64_t o = b; o < e; o += (uint64_t)pg) ((volatile char *)m->map)[o] = 0;
+    }
+    m->done += e - b;
+}
 static void prefault_worker(bfq_outmap *m)
 {
-    const long pg = sysconf(_SC_PAGESIZE);
     for (;;) {
-        if (m->stop.load(std::memory_order_relaxed)) return;
-        const uint64_t b = m->next.fetch_add(PF_SLICE);
-        if (b >= m->preEnd) return;
-        const uint64_t pe = m->preEnd.load();
-        const uint64_t e = b + PF_SLICE < pe ? b + PF_SLICE : pe;
-#ifdef MADV_POPULATE_WRITE
-        if (madvise(m->map + b, (size_t)(e - b), MADV_POPULATE_WRITE) == 0) { m->done += e - b; continue; }
-#endif
-        for (uint64_t o = b; o < e; o += (uint64_t)pg) {         // older kernels: touch every page (the file is new: all zero)
-            if (m->stop.load(std::memory_order_relaxed)) return;
-            ((volatile char *)m->map)[o] = 0;
+        if (m->stop.load(std::memory_order_relaxed)) break;
+        const uint64_t idx = m->next.fetch_add(1);
+        if (idx >= m->nslices || idx * PF_SLICE >= m->preEnd.load()) { m->next.fetch_sub(1); break; }
+        uint8_t z = 0;
+        if (m->state[idx].compare_exchange_strong(z, 1)) { populate_slice(m, idx); m->state[idx].store(2); }
+    }
+    if (--m->alive == 0) m->tHelpersDone = now_s();
+}
+// the bytes [off, off + len) of the mapping are about to be written: returns once their pages are populated
+void bfq_outmap_ensure(bfq_outmap *m, uint64_t off, uint64_t len)
+{
+    if (!m || !len) return;
+    const uint64_t s0 = off / PF_SLICE, s1 = std::min<uint64_t>((off + len - 1) / PF_SLICE, m->nslices - 1);
+    for (uint64_t idx = s0; idx <= s1; idx++) {
+        for (;;) {
+            const uint8_t st = m->state[idx].load();
+            if (st == 2) break;
+            // nobody is going to do it (beyond the pre-fault range, or the helpers have gone): do it here
+            if (st == 0 && (m->alive.load() == 0 || idx * PF_SLICE >= m->preEnd.load() || idx < m->next.load())) {
+                uint8_t z = 0;
+                if (m->state[idx].compare_exchange_strong(z, 1)) { populate_slice(m, idx); m->state[idx].store(2); break; }
+            }
+            usleep(200);
         }
-        m->done += e - b;
     }
 }
 
@@ -274,15 +363,18 @@ bfq_outmap *bfq_outmap_open(int fd, uint64_t map_len, uint64_t prefault_len)
     if (p == MAP_FAILED) { if (ftruncate(fd, 0) != 0) {} return nullptr; }
     bfq_outmap *m = new bfq_outmap();
     m->fd = fd; m->map = (char *)p; m->mapLen = map_len;
+    m->nslices = (map_len + PF_SLICE - 1) / PF_SLICE;
+    m->state = new std::atomic<uint8_t>[m->nslices];
+    for (uint64_t i = 0; i < m->nslices; i++) m->state[i].store(0);
     m->preEnd = prefault_len < map_len ? prefault_len : map_len;
     const uint64_t pe0 = m->preEnd.load();
-    m->t0 = now_s();
     int T = bfq_env().prefaultThreads;
     if (T < 0) {
-        const unsigned hw = std::thread::hardware_concurrency();
-        T = hw >= 16 ? 4 : hw >= 8 ? 2 : 1;
+        T = bfq_cpu_budget() >= 8 ? 2 : 1;
     }
-    if (pe0 < (64ull << 20)) T = 0;                        // small outputs: not worth a thread
+    if (pe0 < (64ull << 20)) T = 0;                              // small outputs: not worth a thread
+    m->alive = T;
+    m->tOpen = now_s();
     for (int t = 0; t < T; t++) m->th.emplace_back(prefault_worker, m);
     return m;
 }
@@ -293,9 +385,9 @@ void bfq_outmap_extend(bfq_outmap *m, uint64_t prefault_len)
 {
     if (!m) return;
     if (prefault_len > m->mapLen) prefault_len = m->mapLen;
-    if (prefault_len <= m->preEnd) return;
-    // the workers read preEnd on every slice: raising it keeps those still alive going; finished ones are not restarted
-    // (the copy itself faults in whatever they did not reach)
+    if (prefault_len <= m->preEnd.load()) return;
+    // the helpers read preEnd on every slice: raising it keeps those still alive going; finished ones are not restarted
+    // (whoever writes there populates what they did not reach)
     m->preEnd = prefault_len;
 }
 // stops the helpers, unmaps, cuts the file to its final length; false if that failed
@@ -305,10 +397,73 @@ bool bfq_outmap_close(bfq_outmap *m, uint64_t final_len)
     m->stop = true;
     for (auto &t : m->th) if (t.joinable()) t.join();
     if (bfq_env().trace)
-        fprintf(stderr, "[bfq io] output mapping %.2f GB: %.2f GB pre-faulted by %zu helper thread(s)\n", final_len / 1e9,
-                (double)m->done.load() / 1e9, m->th.size());
+        fprintf(stderr, "[bfq io] output mapping %.2f GB: %.2f GB prepared (fallocate + populate), %zu helper thread(s) done %.3f s after the file was opened (closed after %.3f s)\n",
+                final_len / 1e9, (double)m->done.load() / 1e9, m->th.size(), m->tHelpersDone > 0 ? m->tHelpersDone - m->tOpen : -1.0, now_s() - m->tOpen);
     bool ok = munmap(m->map, (size_t)m->mapLen) == 0;
     if (final_len != m->mapLen) ok = (ftruncate(m->fd, (off_t)final_len) == 0) && ok;
+    delete[] m->state;
     delete m;
     return ok;
+}
+
+// ---------------------------------------------------------------- what a tool can do before the GPU is even initialised
+// eBWT rows of a FASTQ file, estimated from the complete records among its first bytes (0.98 of it: the estimate sizes the
+// background pre-fault of the outputs before the file has been parsed; a wrong guess costs time, never correctness)
+extern "C" uint64_t bfq_fastq_rows_estimate(int fd, uint64_t len)
+{
+    const size_t want = (size_t)(len < (1u << 20) ? len : (1u << 20));
+    if (!want || fd < 0) return 0;
+    std::vector<uint8_t> b(want);
+    double rpb = 0.45;
+    if (pread(fd, b.data(), want, 0) == (ssize_t)want) {
+        uint64_t rows = 0, used = 0;
+        size_t pos = 0;
+        for (;;) {
+            size_t e[4], p = pos;
+            int k = 0;
+            for (; k < 4; k++) {
+                const void *q = p < want ? memchr(b.data() + p, '\n', want - p) : nullptr;
+                if (!q) break;
+                e[k] = (size_t)((const uint8_t *)q - b.data());
+                p = e[k] + 1;
+            }
+            if (k < 4) break;
+            size_t L = e[1] - (e[0] + 1);
+            if (L && b[e[1] - 1] == '\r') L--;
+            rows += L + 1;
+            used = p;
+            pos = p;
+        }
+        if (used) rpb = (double)rows / (double)used;
+    }
+    if (rpb > 0.5) rpb = 0.5;
+    return (uint64_t)(rpb * (double)len * 0.98);
+}
+
+// A tool opens its outputs first thing and registers them here; the entry point that later gets the same descriptor finds
+// the mapping already there and (mostly) faulted in.
+namespace {
+std::mutex g_regMu;
+std::vector<bfq_outmap *> g_reg;
+}
+extern "C" int bfq_output_prefault(int fd, uint64_t map_len, uint64_t prefault_len)
+{
+    bfq_outmap *m = bfq_outmap_open(fd, map_len, prefault_len);
+    if (!m) return BFQ_E_IO;
+    std::lock_guard<std::mutex> g(g_regMu);
+    g_reg.push_back(m);
+    return BFQ_OK;
+}
+bfq_outmap *bfq_outmap_take(int fd, uint64_t min_len)
+{
+    std::lock_guard<std::mutex> g(g_regMu);
+    for (size_t i = 0; i < g_reg.size(); i++)
+        if (g_reg[i]->fd == fd) {
+            bfq_outmap *m = g_reg[i];
+            g_reg.erase(g_reg.begin() + (long)i);
+            if (m->mapLen >= min_len) return m;
+            bfq_outmap_close(m, 0);                              // too small for what is coming: start over
+            return nullptr;
+        }
+    return nullptr;
 }

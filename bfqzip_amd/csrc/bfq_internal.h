@@ -103,6 +103,8 @@ struct bfq_ctx {
     double profMs[K_NUM];
     u64 profLaunches[K_NUM];
     double profBytes[K_NUM];
+    int profTraceId = -1;               // per-launch times of this kernel id are kept too (bfq_prof_trace), newest last
+    std::vector<float> profTrace;
     void profBegin(int id, double bytes);
     void profEnd();
     void profCollect();   // after a stream synchronise
@@ -115,14 +117,16 @@ struct bfq_ctx {
     struct IoWorker { hipStream_t stream = nullptr; char *stage[2] = {nullptr, nullptr}; hipEvent_t done[2] = {nullptr, nullptr}; };
     IoWorker io[BFQ_IO_MAX_WORKERS];
     int ioWorkers = 0;
-    void ioInit();
+    void ioInit(int want);          // at least min(want, the thread budget) staging workers exist afterwards
     void ioFree();
     struct BfqWriter *writer = nullptr;  // background device -> host / file writes (bfq_write_async, bfq_io.hip)
+    size_t writeHint = 0;               // bytes the caller is going to queue in all: sizes the writer pool when it is created
 
     // one-shot tools (the *_fd entry points): the eBWT and its qualities live outside the arena (in the text buffer, whose
     // FASTQ text is dead once the reads are gathered), so that the arena can be freed while they are still being written;
     // onRows(start, rows) is called whenever rows [start, start + rows) of the eBWT / QS / LCP are final (pile by pile)
     u8 *extBwt = nullptr, *extQual = nullptr;
+    bool lcpScratch = false;            // pile mode: nobody reads the LCP (gsufsort): one pile's worth of scratch instead of 2 n bytes
     std::function<void(u64, u64)> onRows;
 
     // device copy of the FASTQ text of the current call (outside the arena: its record count sizes the arena);
@@ -134,10 +138,13 @@ struct bfq_ctx {
     bool residentValid = false;
     int residentParts = 0;          // ... and where its parts start (entry residentParts = residentLen)
     u64 residentPstart[BFQ_MAX_PARTS + 1] = {0, 0, 0, 0, 0};
+    u64 globN = 0;                  // global mode: the two-symbol pile sizes bfq_glob_pile_counts found for a text of globN rows
+    u64 globCounts[36] = {0};
 };
 // a host-side operand of a transfer: memory, or an open file at an offset (the front-ends' files)
 struct HostRef {
     void *ptr = nullptr; int fd = -1; u64 off = 0;
+    bfq_outmap *om = nullptr;       // ptr lies `off` bytes into this output mapping: pages are populated before they are written
     static HostRef mem(const void *p) { HostRef h; h.ptr = const_cast<void *>(p); return h; }
     static HostRef file(int fd, u64 off = 0) { HostRef h; h.fd = fd; h.off = off; return h; }
     bool null() const { return !ptr && fd < 0; }
@@ -221,8 +228,10 @@ void bfq_emit_bwt(bfq_ctx *c, SortRec rec, u64 n, int termOut, u8 *bwt, u8 *qs, 
 void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total,
                       int termOut, bfq_stats *st);
 // the same, one first-symbol pile at a time (k_piles.hip); workspace bound for pile records of at most `cap` rows
-void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, int termOut, bfq_stats *st);
-size_t bfq_ws_need_piles(u64 n, u64 N, u64 cap, u64 extra);
+struct PileText { u8 *T8, *Q8; u64 *text3; };
+void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, int termOut, bfq_stats *st,
+                     const PileText *pre = nullptr, u64 capTarget = 0);
+size_t bfq_ws_need_piles(u64 n, u64 N, u64 cap, u64 extra, bool lean = false);
 // one pile on its own (global mode): pile-local eBWT / QS / LCP + the sorted records' (w1, w2) words, all in the arena
 struct PileRows { u64 m; u8 *bwt, *qs; u16 *lcp; const u64 *w12; };
 u64 bfq_run_one_pile(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, u32 s, u32 s2, int termOut, PileRows *out);

@@ -22,16 +22,22 @@ struct BfqEnv {
     int fakeDevices = 0;            // BFQ_FAKE_DEVICES=n: pretend n GPUs (slot k -> device k mod the real count): lease tests on one GPU
     bool lease = true;              // BFQ_LEASE=0: no lease files (the caller places the tools itself)
     std::string leaseDir;           // BFQ_LEASE_DIR: where the lock files live (default /dev/shm, else /tmp)
+    bool wsContig = false;          // BFQ_WS_CONTIG=1: ask for a physically contiguous workspace (hipDeviceMallocContiguous), plain hipMalloc if refused
+    unsigned long long abPad = 0;   // BFQ_AB_PAD: bytes left free between the two sort-record buffers (placement experiments)
+    bool abSwap = false;            // BFQ_AB_SWAP=1: the second record buffer below the first (placement experiments)
     bool noOutmap = false;          // BFQ_NO_OUTMAP: the tools write their outputs with pwrite instead of through a mapping (test knob)
     int invertNt = 1;               // BFQ_INVERT_NT=0: plain instead of nontemporal LF-table loads in k_invert
 };
 BfqEnv bfq_env_read();
 const BfqEnv &bfq_env();
+int bfq_cpu_budget();            // CPUs this process may keep busy (cgroup quota, affinity, hardware)
 
 // output file mapped for writing, pre-faulted in the background
 struct bfq_outmap;
 bfq_outmap *bfq_outmap_open(int fd, uint64_t map_len, uint64_t prefault_len);
+bfq_outmap *bfq_outmap_take(int fd, uint64_t min_len);     // a mapping registered by bfq_output_prefault(), or nullptr
 char *bfq_outmap_ptr(bfq_outmap *m);
 uint64_t bfq_outmap_len(bfq_outmap *m);
 void bfq_outmap_extend(bfq_outmap *m, uint64_t prefault_len);
 bool bfq_outmap_close(bfq_outmap *m, uint64_t final_len);
+void bfq_outmap_ensure(bfq_outmap *m, uint64_t off, uint64_t len);   // before copying into [off, off + len)

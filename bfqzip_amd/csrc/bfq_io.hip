@@ -28,9 +28,9 @@ static int io_threads()
 {
     static const int t = [] {
         { int v = bfq_env().ioThreads; if (v >= 1 && v <= BFQ_IO_MAX_WORKERS) return v; }
-        unsigned hw = std::thread::hardware_concurrency();
-        int v = hw >= 32 ? 8 : hw >= 16 ? 4 : hw >= 4 ? 2 : 1;
-        return v;
+        // staging workers beside the main thread, two populate helpers and the runtime's own threads: half the budget
+        const int cpus = bfq_cpu_budget();
+        return cpus >= 16 ? 8 : cpus >= 8 ? 4 : cpus >= 4 ? 2 : 1;
     }();
     return t;
 }
@@ -55,16 +55,15 @@ extern "C" void bfq_host_free(void *p)
     if (p) (void)hipHostFree(p);
 }
 
-void bfq_ctx::ioInit()
+void bfq_ctx::ioInit(int want)
 {
-    if (ioWorkers) return;
-    const int T = io_threads();
-    for (int t = 0; t < T; t++) {
+    const int T = std::min(io_threads(), std::max(want, 1));
+    for (int t = ioWorkers; t < T; t++) {                       // grows on demand, never shrinks
         IoWorker &w = io[t];
         HIP_CHECK(hipStreamCreateWithFlags(&w.stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) HIP_CHECK(hipHostMalloc((void **)&w.stage[k], BFQ_IO_STAGE_BYTES, hipHostMallocDefault));
+        ioWorkers = t + 1;
     }
-    ioWorkers = T;
 }
 static void writer_free(bfq_ctx *c);
 void bfq_ctx::ioFree()
@@ -97,7 +96,11 @@ static bool host_get(const HostRef &h, size_t off, char *dst, size_t sz)
 }
 static bool host_put(const HostRef &h, size_t off, const char *src, size_t sz)
 {
-    if (h.ptr) { memcpy((char *)h.ptr + off, src, sz); return true; }
+    if (h.ptr) {
+        if (h.om) bfq_outmap_ensure(h.om, h.off + off, sz);
+        memcpy((char *)h.ptr + off, src, sz);
+        return true;
+    }
     size_t put = 0;
     while (put < sz) {
         ssize_t w = pwrite(h.fd, src + put, sz - put, (off_t)(h.off + off + put));
@@ -115,8 +118,10 @@ static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
 static void staged_copy(bfq_ctx *c, char *dev, HostRef host, size_t len, bool up)
 {
     const double t0 = io_trace() ? now_s() : 0;
-    c->ioInit();
-    const int T = c->ioWorkers;
+    // one worker per 128 MiB (each costs two pinned 16 MiB buffers the first time): a 200 MB file is not worth sixteen of them
+    const int want = (int)std::min<size_t>(BFQ_IO_MAX_WORKERS, (len + (128u << 20) - 1) / (128u << 20));
+    c->ioInit(want);
+    const int T = std::min(c->ioWorkers, std::max(want, 1));
     const size_t CH = BFQ_IO_STAGE_BYTES;
     const size_t nch = (len + CH - 1) / CH;
     hipError_t errs[BFQ_IO_MAX_WORKERS];
@@ -284,12 +289,13 @@ static void writer_thread(BfqWriter *W, int t)
     }
     flush(0); flush(1);
 }
-static BfqWriter *writer_get(bfq_ctx *c)
+static BfqWriter *writer_get(bfq_ctx *c, size_t firstBytes)
 {
     if (c->writer) return c->writer;
     BfqWriter *W = new BfqWriter();
     W->c = c;
-    const int T = io_threads();
+    // sized by what the caller expects to write in all (bfq_ctx::writeHint) or by the first job: one thread per 128 MiB
+    const int T = (int)std::min<size_t>((size_t)io_threads(), std::max<size_t>(1, (firstBytes + (128u << 20) - 1) / (128u << 20)));
     for (int t = 0; t < T; t++) {
         HIP_CHECK(hipStreamCreateWithFlags(&W->w[t].stream, hipStreamNonBlocking));
         for (int k = 0; k < 2; k++) {
@@ -304,7 +310,7 @@ static BfqWriter *writer_get(bfq_ctx *c)
 void bfq_write_async(bfq_ctx *c, HostRef dst, const void *d_src, size_t len)
 {
     if (!len) return;
-    BfqWriter *W = writer_get(c);
+    BfqWriter *W = writer_get(c, std::max<size_t>(len, c->writeHint));
     hipEvent_t ev;
     HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
     HIP_CHECK(hipEventRecord(ev, c->stream));
@@ -315,7 +321,8 @@ void bfq_write_async(bfq_ctx *c, HostRef dst, const void *d_src, size_t len)
     for (size_t off = 0; off < len; off += CH) {
         WrTask t;
         t.dst = dst;
-        if (dst.ptr) t.dst.ptr = (char *)dst.ptr + off; else t.dst.off = dst.off + off;
+        if (dst.ptr) t.dst.ptr = (char *)dst.ptr + off;
+        t.dst.off = dst.off + off;
         t.src = (const char *)d_src + off;
         t.sz = std::min(CH, len - off);
         t.after = ev;
@@ -374,7 +381,7 @@ BfqAsyncUpload *bfq_upload_begin(bfq_ctx *c, void *d_dst, HostRef src, size_t le
 {
     BfqAsyncUpload *u = new BfqAsyncUpload();
     if (!len) return u;
-    c->ioInit();                                                // on the caller's thread: no race with a later ioInit()
+    c->ioInit(BFQ_IO_MAX_WORKERS);                              // on the caller's thread: no race with a later ioInit()
     for (int t = 0; t < c->ioWorkers; t++)
         for (int k = 0; k < 2; k++)
             if (!c->io[t].done[k]) HIP_CHECK(hipEventCreateWithFlags(&c->io[t].done[k], hipEventDisableTiming));

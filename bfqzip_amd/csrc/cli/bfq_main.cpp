@@ -115,13 +115,15 @@ int main(int argc, char **argv)
         }
     }
     uint64_t n = bwt.size;
-    bfq_ctx *c = create_on_free_gpu(TOOL, &P);
-    if (!c) return 1;
     // the FASTQ text (header line verbatim from -H, else "@"; bases; "+"; qualities -- bfq_int.cpp:797-810)
     // is laid out on the GPU and written straight from the library's staging buffers
     if (headers && !hdr.open(titles)) { fprintf(stderr, "%s: cannot read %s\n", TOOL, titles.c_str()); return 1; }
     OutFile outText;
-    if (!outText.open(output)) { perror("invert"); bfq_destroy(c); return 1; }
+    if (!outText.open(output)) { perror("invert"); return 1; }
+    // at least 2 n bytes of it are certain: their pages are faulted in by helper threads from now on (include/bfqzip_hip.h)
+    (void)bfq_output_prefault(outText.fd, 6 * n + hdr.size + 4096, 2 * n);
+    bfq_ctx *c = create_on_free_gpu(TOOL, &P);
+    if (!c) return 1;
     uint64_t outLen = 0;
     bfq_stats st;
     int lb = (needLcp && n) ? (int)(lcp.size / n) : 0;
@@ -132,6 +134,7 @@ int main(int argc, char **argv)
         return 1;
     }
     bfq_phase("teardown");
+    trace_kernel_times(c, TOOL);
     const bool closed = outText.close();
     bfq_destroy(c);
     if (!closed) { perror("invert"); return 1; }

@@ -38,17 +38,24 @@ int main(int argc, char **argv)
     if (!buf.open(in)) { fprintf(stderr, "%s: cannot read %s\n", tool, in.c_str()); return 1; }
     bfq_params P;
     bfq_default_params(&P);
-    P.piles = 1;                                 // one process, one collection: the smaller pile-by-pile workspace is allocated faster
-    bfq_ctx *c = create_on_free_gpu(tool, &P);
-    if (!c) return 1;
+    P.piles = 1;                                 // one process, one collection: pile by pile in as little HBM as possible (what a process frees, the next one waits for)
     uint64_t n = 0, N = 0;
     OutFile bwt, qs, lcpf;
     bool ok = bwt.open(out + ".bwt") && qs.open(out + ".bwt.qs");
     if (ok && wantLcp) ok = lcpf.open(out + "." + std::to_string(lbytes) + ".lcp");
-    if (!ok) { fprintf(stderr, "%s: cannot create outputs for %s\n", tool, out.c_str()); bfq_destroy(c); return 1; }
+    if (!ok) { fprintf(stderr, "%s: cannot create outputs for %s\n", tool, out.c_str()); return 1; }
+    // the outputs' pages are allocated and zeroed by helper threads from now on -- beside the lease, the start of the HIP
+    // runtime, the upload and the sort (a failure here only means they are written the slow way)
+    const uint64_t est = bfq_fastq_rows_estimate(buf.fd, buf.size), capRows = buf.size / 2 + 64;
+    (void)bfq_output_prefault(bwt.fd, capRows, est);
+    (void)bfq_output_prefault(qs.fd, capRows, est);
+    if (wantLcp) (void)bfq_output_prefault(lcpf.fd, capRows * (uint64_t)lbytes, est * (uint64_t)lbytes);
+    bfq_ctx *c = create_on_free_gpu(tool, &P);
+    if (!c) return 1;
     int rc = bfq_fastq_build_ebwt_fd(c, buf.fd, buf.size, term, bwt.fd, qs.fd, wantLcp ? lcpf.fd : -1, lbytes, &n, &N);
     if (rc) { fprintf(stderr, "%s: %s: %s\n", tool, in.c_str(), bfq_last_error(c)); bfq_destroy(c); return 1; }
     bfq_phase("teardown");
+    trace_kernel_times(c, tool);
     ok = bwt.close() && qs.close();
     ok = lcpf.close() && ok;
     bfq_destroy(c);

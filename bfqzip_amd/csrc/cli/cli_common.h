@@ -57,6 +57,24 @@ static inline bfq_ctx *create_on_free_gpu(const char *tool, const bfq_params *P)
     return c;
 }
 
+// BFQ_TRACE: the kernels' accumulated HIP-event times of this process
+static inline void trace_kernel_times(bfq_ctx *c, const char *tool)
+{
+    if (!getenv("BFQ_TRACE")) return;
+    std::string s = std::string("[bfq kernels] ") + tool + ":";
+    for (int i = 0; i < bfq_prof_count(c); i++) {
+        char name[64];
+        double ms = 0, bytes = 0;
+        uint64_t launches = 0;
+        if (bfq_prof_get(c, i, name, sizeof name, &ms, &launches, &bytes) == 0 && launches) {
+            char b[128];
+            snprintf(b, sizeof b, " %s %.1f ms/%llu", name, ms, (unsigned long long)launches);
+            s += b;
+        }
+    }
+    fprintf(stderr, "%s\n", s.c_str());
+}
+
 struct InFile {
     int fd = -1;
     uint64_t size = 0;

@@ -195,7 +195,9 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
         if (used + tot > BQ_STAGE) {
             if (threadIdx.x == 0) sBase = atomicAdd((unsigned long long *)&a.tail[0], (unsigned long long)used);
             __syncthreads();
-            for (u32 j = threadIdx.x; j < used; j += 256) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+            // (a byte sequence that is no eBWT can enqueue more than the n intervals a real one has: the stores stop at the
+            // queue's end, the host sees the tail beyond it and reports BFQ_E_NOT_EBWT)
+            for (u32 j = threadIdx.x; j < used; j += 256) if (sBase + j < a.n + 64) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
             __syncthreads();
             used = 0;
         }
@@ -206,7 +208,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
     if (used) {
         if (threadIdx.x == 0) sBase = atomicAdd((unsigned long long *)&a.tail[0], (unsigned long long)used);
         __syncthreads();
-        for (u32 j = threadIdx.x; j < used; j += 256) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+        for (u32 j = threadIdx.x; j < used; j += 256) if (sBase + j < a.n + 64) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
     }
     const u64 wsum = bfq_readlane64(bfq_wave_incscan64(written), 63);
     if (lane == 0 && wsum) atomicAdd((unsigned long long *)&a.tail[3], (unsigned long long)wsum);

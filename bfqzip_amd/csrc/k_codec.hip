@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void k_cdc_decode8(const u8 *__restrict__ pay,
         const u8 *q = pay + off[g];
         const u32 nbytes = segBytes[g];
         u32 x = (u32)q[0] | ((u32)q[1] << 8) | ((u32)q[2] << 16) | ((u32)q[3] << 24);
+        if (x < CQ_L) { atomicAdd(bad, 1u); continue; }             // an encoder's final state is never below the renormalisation bound
         u32 used = 4;                                              // bytes of the stream consumed so far
         u64 ib = 0;                                                // bytes not yet consumed, the next one in the low byte
         u32 ni = 0;
@@ -270,9 +271,13 @@ __global__ __launch_bounds__(256) void k_cdc_decode8(const u8 *__restrict__ pay,
             }
             x = f * (x >> CQ_SCALE) + slot - c0;
             while (x < CQ_L) {
-                if (ni == 0) { ib = (used < nbytes) ? *(const u64 *)(q + used) : 0ull; ni = 8; }   // (the buffer is padded by 16 bytes; a damaged stream reads zeros, not memory)
+                // a damaged stream reads zeros past its segment, not memory (the buffer is padded by 16 bytes) -- and only a
+                // few of them: a state that stays 0 would otherwise refill for ever (a zero-filled page inside a payload)
+                if (used >= nbytes + 4) { ok = false; break; }
+                if (ni == 0) { ib = (used < nbytes) ? *(const u64 *)(q + used) : 0ull; ni = 8; }
                 x = (x << 8) | (u32)(ib & 0xFFu); ib >>= 8; ni--; used++;
             }
+            if (!ok) break;
             ob |= (u64)salpha[s] << (8u * (u32)((i - b) & 7u));
             if (((i - b) & 7u) == 7u) { *(u64 *)(out + i - 7) = ob; ob = 0; }
             ctx = cdc_next_ctx(ctx, s, win, m);
@@ -281,6 +286,33 @@ __global__ __launch_bounds__(256) void k_cdc_decode8(const u8 *__restrict__ pay,
         if (used > nbytes) ok = false;
         if (!ok) atomicAdd(bad, 1u);
     }
+}
+
+// checksum of the raw stream (oracle/bfq_codec_ref.c states it): a sum of position-keyed terms, one 64-bit word per lane
+#define CQ_HDR 44u                                              // magic, raw_len, five u32, checksum
+__host__ __device__ static inline u64 cdc_mix64(u64 z) { z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; return z; }
+__global__ __launch_bounds__(256) void k_cdc_checksum(const u8 *__restrict__ in, u64 n, u64 *__restrict__ out)
+{
+    const u64 nw = (n + 7) / 8;
+    u64 sum = 0;
+    for (u64 j = (u64)blockIdx.x * blockDim.x + threadIdx.x; j < nw; j += (u64)gridDim.x * blockDim.x) {
+        u64 w = 0;
+        if (8 * j + 8 <= n) __builtin_memcpy(&w, in + 8 * j, 8);   // any alignment
+        else for (u64 b = 0; 8 * j + b < n; b++) w |= (u64)in[8 * j + b] << (8 * b);
+        sum += cdc_mix64(w + (j + 1) * 0x9E3779B97F4A7C15ull);
+    }
+    sum = bfq_readlane64(bfq_wave_incscan64(sum), 63);
+    if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long *)out, (unsigned long long)sum);
+}
+// d_tmp: 8 bytes of device scratch
+static u64 cdc_checksum_device(bfq_ctx *c, const u8 *d_in, u64 n, u64 *d_tmp)
+{
+    HIP_CHECK(hipMemsetAsync(d_tmp, 0, 8, c->stream));
+    if (n) KLAUNCH(c, K_CODEC, (double)n, k_cdc_checksum, bfq_grid((n + 7) / 8, 256 * 16), 256, d_in, n, d_tmp);
+    u64 sum = 0;
+    HIP_CHECK(hipMemcpyAsync(&sum, d_tmp, 8, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+    return cdc_mix64(n ^ sum);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------
@@ -338,7 +370,7 @@ static u64 get64(const u8 *p) { return (u64)get32(p) | ((u64)get32(p + 4) << 32)
 u64 bfq_codec_bound(u64 n)
 {
     const u64 nseg = (n + 1023) / 1024;
-    return 32 + 36 + 256 + 512 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64;
+    return 32 + CQ_HDR + 256 + 512 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64;
 }
 // device workspace of one compress / decompress call
 u64 bfq_codec_workspace(u64 n)
@@ -352,6 +384,7 @@ u64 bfq_codec_workspace(u64 n)
 static u64 rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
 {
     const size_t mk = c->mark();
+    const u64 checksum = cdc_checksum_device(c, d_in, n, c->alloc<u64>(1));
     u32 *d_present = c->alloc<u32>(256);
     HIP_CHECK(hipMemsetAsync(d_present, 0, 1024, c->stream));
     if (n) KLAUNCH(c, K_CODEC, (double)n, k_cdc_present, bfq_grid(n, 256 * 64), 256, d_in, n, d_present);
@@ -396,7 +429,7 @@ static u64 rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u6
         u32 acc = 0;
         for (u32 s = 0; s < A; s++) { cum[x * A + s] = (u16)acc; acc += freq[x * A + s]; }
     }
-    const u64 hdr = 36 + 256 + 2ull * A + used.size() + nused * A * 2 + 4ull * m.nseg;
+    const u64 hdr = CQ_HDR + 256 + 2ull * A + used.size() + nused * A * 2 + 4ull * m.nseg;
     if (hdr > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
     std::vector<u32> fcv(E);
     for (u64 x = 0; x < E; x++) fcv[x] = (u32)freq[x] | ((u32)cum[x] << 16);
@@ -420,12 +453,13 @@ static u64 rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u6
     }
     std::vector<u8> h(hdr);
     u8 *p = h.data();
-    memcpy(p, "BFQRANS1", 8); put64(p + 8, n);
+    memcpy(p, "BFQRANS2", 8); put64(p + 8, n);
     put32(p + 16, m.seg); put32(p + 20, m.nseg); put32(p + 24, A); put32(p + 28, m.k); put32(p + 32, CQ_SCALE);
-    memcpy(p + 36, alphabet, 256);
-    for (u32 s = 0; s < A; s++) { p[36 + 256 + 2 * s] = (u8)dflt[s]; p[36 + 256 + 2 * s + 1] = (u8)(dflt[s] >> 8); }
-    memcpy(p + 36 + 256 + 2ull * A, used.data(), used.size());
-    u8 *rows = p + 36 + 256 + 2ull * A + used.size();
+    put64(p + 36, checksum);
+    memcpy(p + CQ_HDR, alphabet, 256);
+    for (u32 s = 0; s < A; s++) { p[CQ_HDR + 256 + 2 * s] = (u8)dflt[s]; p[CQ_HDR + 256 + 2 * s + 1] = (u8)(dflt[s] >> 8); }
+    memcpy(p + CQ_HDR + 256 + 2ull * A, used.data(), used.size());
+    u8 *rows = p + CQ_HDR + 256 + 2ull * A + used.size();
     for (u64 x = 0; x < nctx; x++) {
         if (!((used[x >> 3] >> (x & 7)) & 1)) continue;
         for (u32 s = 0; s < A; s++) { rows[0] = (u8)freq[x * A + s]; rows[1] = (u8)(freq[x * A + s] >> 8); rows += 2; }
@@ -442,8 +476,8 @@ static u64 rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u6
 struct CdcHeader { CdcModel m; u64 hdr; std::vector<u8> alphabet; std::vector<u16> freq, cum; std::vector<u32> segBytes; };
 static void cdc_parse(const u8 *in, u64 len, CdcHeader &H)
 {
-    const BfqError bad{BFQ_E_ARG, "not a BFQRANS1 stream (or a damaged one)"};
-    if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) throw bad;
+    const BfqError bad{BFQ_E_ARG, "not a BFQRANS2 stream (or a damaged one)"};
+    if (len < CQ_HDR + 256 || memcmp(in, "BFQRANS2", 8)) throw bad;
     CdcModel &m = H.m;
     m.n = get64(in + 8);
     const u32 seg = get32(in + 16), scale = get32(in + 32);
@@ -454,9 +488,9 @@ static void cdc_parse(const u8 *in, u64 len, CdcHeader &H)
     for (u32 j = 0; j < m.k; j++) { nctx *= m.A; if (nctx > CQ_MAX_TABLE) throw bad; }
     if (nctx * m.A > CQ_MAX_TABLE) throw bad;
     m.top = (u32)nctx;
-    H.alphabet.assign(in + 36, in + 36 + 256);
-    if (36 + 256 + 2ull * m.A + (nctx + 7) / 8 > len) throw bad;
-    const u8 *dfl = in + 36 + 256;
+    H.alphabet.assign(in + CQ_HDR, in + CQ_HDR + 256);
+    if (CQ_HDR + 256 + 2ull * m.A + (nctx + 7) / 8 > len) throw bad;
+    const u8 *dfl = in + CQ_HDR + 256;
     const u8 *used = dfl + 2ull * m.A;
     const u8 *rows = used + (nctx + 7) / 8;
     H.freq.assign(nctx * m.A, 0); H.cum.assign(nctx * m.A, 0);
@@ -494,7 +528,7 @@ u64 bfq_codec_raw_len(const u8 *h_in, u64 len)
     u64 pos = 0, raw = 0;
     do {
         const bool lx = len - pos >= 32 && !memcmp(h_in + pos, "BFQLINE1", 8);
-        if (!lx && (len - pos < 36 + 256 || memcmp(h_in + pos, "BFQRANS1", 8))) throw BfqError{BFQ_E_ARG, "not a BFQRANS1 stream"};
+        if (!lx && (len - pos < CQ_HDR + 256 || memcmp(h_in + pos, "BFQRANS2", 8))) throw BfqError{BFQ_E_ARG, "not a BFQRANS2 stream"};
         raw += get64(h_in + pos + 8);
         pos += bfq_codec_member_len(h_in + pos, len - pos);
     } while (pos < len);
@@ -537,8 +571,10 @@ static u64 rans_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u6
     u32 bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
     c->sync();
+    const u64 sum = bad ? 0 : cdc_checksum_device(c, d_out, m.n, c->alloc<u64>(1));
     c->release(mk);
-    if (bad) throw BfqError{BFQ_E_ARG, "damaged BFQRANS1 stream"};
+    if (bad) throw BfqError{BFQ_E_ARG, "damaged BFQRANS2 stream"};
+    if (sum != get64(h_in + 36)) throw BfqError{BFQ_E_ARG, "damaged BFQRANS2 stream (checksum of the decoded bytes)"};
     return m.n;
 }
 
@@ -668,7 +704,7 @@ u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 
     const BfqError bad{BFQ_E_ARG, "damaged BFQLINE1 stream"};
     const u64 n = get64(h_in + 8), nl = get64(h_in + 24);
     if (n > cap || get32(h_in + 16) != CQ_LINE_R || nl < 2 || nl > n) throw bad;
-    if (len - 32 < 36 + 256 || memcmp(h_in + 32, "BFQRANS1", 8)) throw bad;
+    if (len - 32 < CQ_HDR + 256 || memcmp(h_in + 32, "BFQRANS2", 8)) throw bad;
     const u64 xl = get64(h_in + 32 + 8);
     if (xl > n + nl) throw bad;
     const size_t mk = c->mark();

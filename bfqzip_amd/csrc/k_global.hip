@@ -123,6 +123,8 @@ extern "C" int bfq_glob_pile_counts(bfq_ctx *c, const uint8_t *d_T8, uint64_t n,
         c->reserve(40 * (n / BFQ_RS_BLOCK_ELEMS + 64) * 8 + (64u << 20));
         memset(counts36, 0, 36 * sizeof(uint64_t));
         if (n) bfq_pile_pair_counts(c, d_T8, n, (u64 *)counts36);
+        c->globN = n;                                           // bfq_glob_run_pile sizes its workspace from these
+        memcpy(c->globCounts, counts36, sizeof c->globCounts);
     });
 }
 
@@ -152,8 +154,10 @@ extern "C" int bfq_glob_run_pile(bfq_ctx *c, const uint8_t *d_T8, const uint8_t 
         if (s < 1 || s > 5 || s2 < 0 || s2 > 5) throw BfqError{BFQ_E_ARG, "pile symbols: first 1..5 (A C G N T), second 0..5"};
         if (c->P.K < 2) throw BfqError{BFQ_E_ARG, "global mode needs -k >= 2 (clusters must not cross the two-symbol piles)"};
         if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^37 rows)"};
-        // text3 + block counts + one pile of at most n rows: sized generously from n (a pile holds about n / 16)
-        const u64 cap = n / 4 + (1u << 20);
+        // text3 + block counts + the records of this pile: its size is known when bfq_glob_pile_counts ran on this text (low-
+        // complexity or amplicon libraries put far more than the usual n / 16 into one pile); else sized generously from n
+        const u64 known = (c->globN == n) ? c->globCounts[6 * s + s2] : 0;
+        const u64 cap = (known ? known : n / 4) + (1u << 20);
         c->reserve(8 * (n / 21 + 8) + 40 * (n / BFQ_RS_BLOCK_ELEMS + 64) * 8 + 30 * (cap + 256) + 12 * 256 * (ceil_div(cap + 1, bfq_radix_block_elems(cap)) + 8200) + (cap + 4096) / 32768 * 64 + (128u << 20));
         c->zeroCounters();
         const u64 nwords = n / BFQ_SYMS_PER_WORD + 3;

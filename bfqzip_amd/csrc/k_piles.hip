@@ -61,61 +61,67 @@ __global__ __launch_bounds__(256) void k_pile_count(const u8 *__restrict__ T8, u
 }
 
 // records of the suffixes that start with symbol `code`, in text order: block b's go to [blkOff[b], blkOff[b + 1])
-// (code2 == 7: any second symbol)
+// (code2 == 7: any second symbol).  16 positions per thread from one 16-byte load each of T8 and Q8 (both 16-byte aligned,
+// PB a multiple of 16), one block scan per 4096 positions: the scan of the whole text costs ~3 ms at 4.5 G positions, which
+// matters when a collection is cut into 20-25 two-symbol piles (one scan per pile).
 __global__ __launch_bounds__(256) void k_build_keys_pile(const u8 *__restrict__ T8, const u8 *__restrict__ Q8, const u64 *__restrict__ text3,
                                                          u64 n, u32 code, u32 code2, const u64 *__restrict__ blkOff, SortRec out, u64 nb)
 {
     __shared__ u32 scan[4];
-    const u32 sw = 1024 / BFQ_SYMS_PER_WORD, so = 1024 - sw * BFQ_SYMS_PER_WORD;
+    constexpr u32 SWEEP = 4096;
+    const u32 sw = SWEEP / BFQ_SYMS_PER_WORD, so = SWEEP - sw * BFQ_SYMS_PER_WORD;
     for (u64 hb = blockIdx.x; hb < nb; hb += gridDim.x) {
         const u64 bbase = hb * (u64)PB;
         u64 bend = bbase + PB;
         if (bend > n) bend = n;
         u64 dst = blkOff[hb];
-        u64 p0 = bbase + (u64)threadIdx.x * 4;
+        u64 p0 = bbase + (u64)threadIdx.x * 16;
         u64 w0 = p0 / BFQ_SYMS_PER_WORD;
         u32 o0 = (u32)(p0 - w0 * BFQ_SYMS_PER_WORD);
-        for (u64 sweep = bbase; sweep < bend; sweep += 1024, p0 += 1024) {     // uniform trip count: barriers inside
-            u32 c5 = 0, cm = 0, cn = 0;                                      // codes of positions p0 .. p0+3, of p0-1 .. p0+2, of p0+1 .. p0+4
-            u32 q4 = 0;
+        for (u64 sweep = bbase; sweep < bend; sweep += SWEEP, p0 += SWEEP) {   // uniform trip count: barriers inside
+            u32 c[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+            u32 before = 0, after = 0, qbefore = (u32)'#';
             u32 match = 0;
             if (p0 < bend) {
-                if (p0 >= 1 && p0 + 5 <= n) {
-                    c5 = *(const u32 *)(T8 + p0); cm = *(const u32 *)(T8 + p0 - 1); q4 = *(const u32 *)(Q8 + p0 - 1); cn = *(const u32 *)(T8 + p0 + 1);
-                } else {
-                    for (int k = 0; k < 4; k++) {
-                        const u64 t = p0 + k;
-                        if (t < n) c5 |= (u32)T8[t] << (8 * k);
-                        if (t + 1 < n) cn |= (u32)T8[t + 1] << (8 * k);
-                        if (t >= 1 && t - 1 < n) { cm |= (u32)T8[t - 1] << (8 * k); q4 |= (u32)Q8[t - 1] << (8 * k); }
-                    }
-                }
+                const uint4 cx = *(const uint4 *)(T8 + p0);              // T8 / Q8 are padded by 64 bytes
+                const uint4 qx = *(const uint4 *)(Q8 + p0);
+                c[0] = cx.x; c[1] = cx.y; c[2] = cx.z; c[3] = cx.w;
+                q[0] = qx.x; q[1] = qx.y; q[2] = qx.z; q[3] = qx.w;
+                if (p0 >= 1) { before = T8[p0 - 1]; qbefore = Q8[p0 - 1]; }
+                if (p0 + 16 < n) after = T8[p0 + 16];
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    if (p0 + k < bend && ((c5 >> (8 * k)) & 0xFFu) == code && (code2 == 7u || ((cn >> (8 * k)) & 0xFFu) == code2)) match |= 1u << k;
+                for (int k = 0; k < 16; k++) {
+                    const u32 ck = (c[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+                    const u32 nk = k < 15 ? (c[(k + 1) >> 2] >> (8 * ((k + 1) & 3))) & 0xFFu : after;
+                    if (p0 + k < bend && ck == code && (code2 == 7u || nk == code2)) match |= 1u << k;
+                }
             }
             u32 tot;
             const u32 ex = bfq_block_exscan32((u32)__popc(match), scan, &tot);
             if (match) {
-                const u64 t0 = text3[w0], t1 = text3[w0 + 1], t2 = text3[w0 + 2];    // 4 windows span at most 3 words
-                u64 wd = w0, d = dst + ex;
-                u32 o = o0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if ((match >> k) & 1u) {
-                        const u64 a = (wd == w0) ? t0 : t1, bnext = (wd == w0) ? t1 : t2;
-                        const u32 o3 = o * 3u;
-                        const u64 hi = (a << o3) & BFQ_M63;
-                        const u64 lo = o3 ? (bnext >> (63u - o3)) : 0ull;
-                        const u64 sk = bfq_skey_of(bfq_mask_key(hi | lo));
-                        const u32 pc = (cm >> (8 * k)) & 0xFFu;
-                        const u32 pq = pc ? (q4 >> (8 * k)) & 0xFFu : (u32)'#';
-                        const u64 pay = bfq_pack_val(p0 + k, pc, pq);
-                        out.w0[d] = bfq_rec_w0(sk);
-                        out.w12[d] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(sk, pay);
-                        d++;
-                    }
-                    if (++o == BFQ_SYMS_PER_WORD) { o = 0; wd++; }
+                const u64 t0 = text3[w0], t1 = text3[w0 + 1], t2 = text3[w0 + 2];    // 16 windows span at most 3 words
+                const u64 clo = (u64)c[0] | ((u64)c[1] << 32), chi = (u64)c[2] | ((u64)c[3] << 32);
+                const u64 qlo = (u64)q[0] | ((u64)q[1] << 32), qhi = (u64)q[2] | ((u64)q[3] << 32);
+                u64 d = dst + ex;
+                // one matching position per iteration and lane (a lane holds ~1 match of a two-symbol pile, ~4 of a
+                // one-symbol pile): the key packing runs max-matches-per-lane times, not 16 times, per wavefront
+                for (u32 mm = match; mm; mm &= mm - 1) {
+                    const u32 k = (u32)__builtin_ctz(mm);
+                    const u32 ok = o0 + k;                                           // <= 35
+                    const bool second = ok >= BFQ_SYMS_PER_WORD;
+                    const u32 o3 = (second ? ok - BFQ_SYMS_PER_WORD : ok) * 3u;
+                    const u64 a = second ? t1 : t0, bnext = second ? t2 : t1;
+                    const u64 hi = (a << o3) & BFQ_M63;
+                    const u64 lo = o3 ? (bnext >> (63u - o3)) : 0ull;
+                    const u64 sk = bfq_skey_of(bfq_mask_key(hi | lo));
+                    const u32 kp = k - 1u;                                           // previous position inside the 16 (k > 0)
+                    const u32 pc = k ? (u32)(((kp < 8 ? clo : chi) >> (8 * (kp & 7))) & 0xFFu) : before;
+                    const u32 pqr = k ? (u32)(((kp < 8 ? qlo : qhi) >> (8 * (kp & 7))) & 0xFFu) : qbefore;
+                    const u32 pq = pc ? pqr : (u32)'#';
+                    const u64 pay = bfq_pack_val(p0 + k, pc, pq);
+                    out.w0[d] = bfq_rec_w0(sk);
+                    out.w12[d] = ((u64)bfq_rec_w2(pay) << 32) | bfq_rec_w1(sk, pay);
+                    d++;
                 }
             }
             dst += tot;
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void k_term_pile(const u8 *__restrict__ T8, co
         if (e > b) { code = T8[tp - 1]; q = Q8[tp - 1]; }
         bwt[i] = code ? bfq_code_sym(code) : (u8)termOut;
         qs[i] = (u8)q;
-        lcp[i] = 0;
+        if (lcp) lcp[i] = 0;
     }
 }
 
@@ -148,35 +154,49 @@ __global__ void k_refine_reset(DevCounters *cnt)
     cnt->bigCount = 0; cnt->hugeCount = 0; cnt->hugeRows = 0;
 }
 
-// workspace bound of the pile mode (pile records for at most `cap` rows)
-size_t bfq_ws_need_piles(u64 n, u64 N, u64 cap, u64 extra)
+// workspace bound of the pile mode (pile records for at most `cap` rows).  lean (the one-shot tools): the eBWT and its
+// qualities live outside the arena, the text arrays are given, and the LCP is a per-pile scratch nobody reads.
+size_t bfq_ws_need_piles(u64 n, u64 N, u64 cap, u64 extra, bool lean)
 {
     u64 nb = n / 32768 + 2, nbc = ceil_div(cap + 1, bfq_radix_block_elems(cap)) + 8200;   // a smaller pile may use smaller radix blocks
     size_t need = 0;
-    need += 4 * (n + 256) + 4096;                                // bwt, qual, lcp16
-    need += 8 * (n / 21 + 8) + 2 * (n + 256);                    // packed text, T8, Q8
+    if (lean) need += 2 * (cap + 256) + 4096;                    // lcp16 of one pile
+    else {
+        need += 4 * (n + 256) + 4096;                            // bwt, qual, lcp16
+        need += 8 * (n / 21 + 8) + 2 * (n + 256);                // packed text, T8, Q8
+    }
     need += 6 * 4 * (cap + 256);                                 // sort records of one pile, ping-pong
     need += 256 * nbc * 12 + (nbc + 4096) * 64;                  // radix histograms + scan partials
-    need += 6 * 12 * nb + 16 * (N + 64);                         // block counts / offsets per symbol, read offsets
+    need += 2 * 6 * 12 * nb + 16 * (N + 64);                     // block counts / offsets per symbol (twice: a split pile), read offsets
     need += extra + (64u << 20);
     return need;
 }
 
-void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, int termOut, bfq_stats *st)
+// pre != nullptr: the text arrays exist already (one-shot tools: they live in an allocation of their own, so that the
+// arena can be sized from the actual pile sizes).  capTarget != 0: piles above it are split by their second symbol even
+// when they would fit.  c->lcpScratch: nobody wants the LCP -- every pile writes its entries to the same scratch.
+void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, int termOut, bfq_stats *st,
+                     const PileText *pre, u64 capTarget)
 {
     const u64 n = total + N;
     if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^37 rows)"};
     c->n = n; c->N = N;
     c->d_bwt = c->extBwt ? c->extBwt : c->alloc<u8>(n + 64);
     c->d_qual = c->extQual ? c->extQual : c->alloc<u8>(n + 64);
-    c->d_lcp = c->alloc<u16>(n + 64);
+    const bool scratch = c->lcpScratch;
+    c->d_lcp = scratch ? nullptr : c->alloc<u16>(n + 64);
     c->d_gcnt = nullptr; c->gcntTerm = -1;                       // symbol counts per group are not produced pile by pile
     if (!n) return;
     const size_t m0 = c->mark();
     const u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
-    u64 *text3 = c->alloc<u64>(nwords);
-    u8 *T8 = c->alloc<u8>(n + 64), *Q8 = c->alloc<u8>(n + 64);
-    bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
+    u64 *text3;
+    u8 *T8, *Q8;
+    if (pre) { text3 = pre->text3; T8 = pre->T8; Q8 = pre->Q8; }
+    else {
+        text3 = c->alloc<u64>(nwords);
+        T8 = c->alloc<u8>(n + 64); Q8 = c->alloc<u8>(n + 64);
+        bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
+    }
     const u64 nb = ceil_div(n, PB);
     u32 *cntBlk = c->alloc<u32>(6 * nb);
     u64 *blkOff = c->alloc<u64>(6 * nb + 8);
@@ -191,8 +211,9 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     if (N) KLAUNCH(c, K_EMIT, 12.0 * (double)N, k_term_pile, bfq_grid(N, 256), 256, (const u8 *)T8, (const u8 *)Q8, d_roff, N,
                    (u32)(termOut & 0xFF), c->d_bwt, c->d_qual, c->d_lcp);
     if (c->onRows) c->onRows(0, N);
+
     const size_t avail = c->wsCap - c->wsTop;
-    auto fits = [&](u64 m) { return (size_t)(24 * (m + 256) + 12 * 256 * (ceil_div(m + 1, bfq_radix_block_elems(m)) + 8) + (m / 32768 + 4096) * 64 + (48u << 20)) <= avail; };
+    auto fits = [&](u64 m) { return (size_t)(24 * (m + 256) + 12 * 256 * (ceil_div(m + 1, bfq_radix_block_elems(m)) + 8) + (m / 32768 + 4096) * 64 + (scratch ? 2 * (m + 256) : 0) + (48u << 20)) <= avail; };
     // one pile (first symbol s, second symbol s2 or 7 = any) of m suffixes -> rows [start, start + m)
     auto run_pile = [&](u32 s, u32 s2, u64 m, u64 start, const u64 *off) {
         const size_t mp = c->mark();
@@ -205,7 +226,8 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
         bfq_radix_sort(c, B, A, m);                               // five passes: B -> A
         c->release(mB);
         hipLaunchKernelGGL(k_refine_reset, dim3(1), dim3(1), 0, c->stream, c->d_cnt);
-        bfq_refine(c, A, text3, m, c->d_lcp + start, st);
+        u16 *lcpOut = scratch ? c->alloc<u16>(m + 64) : c->d_lcp + start;
+        bfq_refine(c, A, text3, m, lcpOut, st);
         bfq_emit_bwt(c, A, m, termOut, c->d_bwt + start, c->d_qual + start, nullptr);
         c->release(mp);
     };
@@ -213,7 +235,7 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     for (u32 s = 1; s <= 5; s++) {
         const u64 m = tot[s];
         if (!m) continue;
-        if (fits(m) && !c->env.pilesSplit) { run_pile(s, 7u, m, start, blkOff + (u64)s * nb); if (c->onRows) c->onRows(start, m); start += m; continue; }
+        if (fits(m) && !c->env.pilesSplit && !(capTarget && m > capTarget)) { run_pile(s, 7u, m, start, blkOff + (u64)s * nb); if (c->onRows) c->onRows(start, m); start += m; continue; }
         // a pile beyond the workspace (skewed base composition, low-complexity reads): once more by its second symbol
         const size_t ms = c->mark();
         u32 *cnt2 = c->alloc<u32>(6 * nb);
@@ -235,7 +257,7 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
                 throw BfqError{BFQ_E_NOMEM, b};
             }
             run_pile(s, s2, m2, start, off2 + (u64)s2 * nb);
-            if (!firstSub) {                                      // the row before shares exactly the first symbol
+            if (!firstSub && !scratch) {                          // the row before shares exactly the first symbol
                 const u16 one = 1;
                 HIP_CHECK(hipMemcpyAsync(c->d_lcp + start, &one, 2, hipMemcpyHostToDevice, c->stream));
                 c->sync();

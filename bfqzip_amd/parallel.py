@@ -180,7 +180,7 @@ def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fas
     """The whole multi-GPU job.  eng: Engine-like (fastq_job, text_line_counts/text_nth_newline via `eng.host`).
     Returns per-rank totals {"blocks", "reads", "bases", "stats"} (stats summed over this rank's blocks).
     compress: step 5 too (BFQzip.py:253-275) -- every block's share of every output goes through the stream codec
-    (eng.stream_compress) and the files `<name>.bsc` hold one BFQRANS1 container per block, in block order
+    (eng.stream_compress) and the files `<name>.bsc` hold one BFQRANS2 container per block, in block order
     (`bsc d` / stream_decompress read them back as one stream)."""
     host = eng.host
     bufs = [map_file(p) for p in inputs]
@@ -279,6 +279,13 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
         if dev.type == "cuda":
             torch.cuda.synchronize()
         now = time.perf_counter(); tm[name] = round(tm.get(name, 0.0) + now - t_last[0], 4); t_last[0] = now
+
+    def tsync():
+        """The engine runs on its own non-blocking stream (bfq_api.hip: hipStreamNonBlocking) and returns synchronised; what
+        torch has queued on ITS stream (clones, copies, collectives) must be complete before the engine reads or overwrites
+        those tensors -- stated here explicitly instead of resting on the timing helper."""
+        if dev.type == "cuda":
+            torch.cuda.current_stream().synchronize()
     nf = len(inputs)
     W, r = comm.world, comm.rank
     bufs = [map_file(p) for p in inputs]
@@ -298,7 +305,9 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
     flat = np.concatenate([[0], np.cumsum(sz.T.reshape(-1))]).astype(np.int64)
     base = flat[:-1].reshape(nf, W)
     n = int(flat[-1])
-    t8 = torch.empty(max(n, 1), dtype=torch.uint8, device=dev); q8 = torch.empty_like(t8)
+    # 64 bytes of padding: the pile kernels read the text 16 bytes at a time (k_piles.hip)
+    t8 = torch.empty(n + 64, dtype=torch.uint8, device=dev); q8 = torch.empty_like(t8)
+    t8[n:] = 0; q8[n:] = 0
     myrows = [int(sz[r][f]) for f in range(nf)]
     if sum(myrows):
         lt = torch.empty(sum(myrows), dtype=torch.uint8, device=dev); lq = torch.empty_like(lt)
@@ -318,10 +327,12 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
     tot = {"blocks": 1, "reads": sum(Np), "bases": sum(Tp), "stats": {}, "seconds": tm}
     sym = torch.empty_like(t8); qual = torch.empty_like(t8)
     if n:
+        tsync()
         counts = eng.glob_pile_counts(t8, n)
         mine = deal_piles(counts, W)[r]
         eng.glob_init_out(t8, q8, n, sym, qual)
         osym, oqual = sym.clone(), qual.clone()
+        tsync()                                                      # the clones are read before the piles edit sym / qual
         for s, s2 in mine:
             st = eng.glob_run_pile(t8, q8, n, s, s2, sym, qual)
             for key, v in st.items():
@@ -339,6 +350,7 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
         lap("delta all-reduce")
     else:
         dna = torch.empty(0, dtype=torch.uint8, device=dev); qs = dna.clone()
+    tsync()
     res = eng.glob_finish(dna, qs, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr, text_len=int(tlen), nparts=nf)
     # outputs at their final offsets: output f = the shares of part f of all ranks, in rank order
     kinds = [k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w]

@@ -163,6 +163,15 @@ int bfq_fastq_build_ebwt_fd(bfq_ctx *c, int fastq_fd, uint64_t len, int term_out
                             int lcp_fd, int lcp_bytes, uint64_t *n_rows, uint64_t *n_reads);
 int bfq_smooth_invert_fastq_fd(bfq_ctx *c, int bwt_fd, int bwtqs_fd, int lcp_fd, int lcp_bytes, uint64_t n,
                                int headers_fd, uint64_t headers_len, int out_fd, uint64_t *out_len, bfq_stats *st);
+/* What a tool can start before the GPU is initialised: bfq_output_prefault() sizes an output descriptor to map_len bytes,
+ * maps it and lets helper threads fault in its first prefault_len bytes in the background (the page-cache pages of a 9 GB
+ * output are allocated and zeroed by the kernel at ~6 GB/s; done beside the upload and the GPU work, the final copy runs at
+ * memcpy speed).  The *_fd entry point that is later handed the same descriptor picks the mapping up and cuts the file to
+ * its real length.  Bounds: eBWT / QS files <= len / 2 + 64 bytes for a FASTQ of len bytes, bfq_fastq_rows_estimate() =
+ * the likely row count (from the first records of the file); the FASTQ text bfq_int writes is >= 2 n and <= 6 n + the
+ * header file + 4096 bytes for an eBWT of n rows.  Optional: without it the entry points do the same from their first line. */
+int      bfq_output_prefault(int fd, uint64_t map_len, uint64_t prefault_len);
+uint64_t bfq_fastq_rows_estimate(int fastq_fd, uint64_t len);
 
 /* ---- one block of BFQzip_parallel.py as one call (BFQzip_parallel.py:277-285 runs `BFQzip.py <block> --rebuild -0
  * [--headers]` per block; :325-360 appends mate block k of file 2 to block k of file 1; :153-172 cuts the
@@ -185,7 +194,7 @@ typedef struct bfq_fastq_job {
     uint64_t fastq_len, stream_len, hdr_len, n_reads, total_bases;
     uint64_t part_reads[BFQ_MAX_PARTS + 1], part_fastq_off[BFQ_MAX_PARTS + 1],
              part_stream_off[BFQ_MAX_PARTS + 1], part_hdr_off[BFQ_MAX_PARTS + 1];
-    /* steps 1-5 in one call: the streams leave as BFQRANS1 containers (bfq_stream_compress, below) instead of raw bytes --
+    /* steps 1-5 in one call: the streams leave as BFQRANS2 containers (bfq_stream_compress, below) instead of raw bytes --
      * what `BFQzip.py --m2/--m3` without -0 produces through 7z / bsc (BFQzip.py:253-275).  The raw streams never cross
      * the bus.  stream_len / hdr_len stay the RAW lengths; *_bytes = what was written to out_dna / out_qs / out_hdr.
      * Capacities: bfq_stream_bound(raw length) always suffices (a tiny stream's container is larger than the stream; the raw
@@ -262,7 +271,7 @@ int bfq_synth_fastq(bfq_ctx *c, const bfq_synth *s, uint8_t *h_out, uint64_t cap
  * Replaces step 5 of the reference, which hands every stream to an external tool: `7z a -mm=PPMd <f>.7z <f>`
  * (step5, BFQzip.py:253-263) or `external/libbsc/bsc e <f> <f>.bsc -T` (step5b, BFQzip.py:265-275).  The front-end
  * dropin/external/libbsc/bsc takes that command line (`bsc e IN OUT [options]`, `bsc d IN OUT`).
- * The container ("BFQRANS1": static order-k model + range-ANS, segments of 8192 symbols) is this project's own --
+ * The container ("BFQRANS2": static order-k model + range-ANS, segments of 8192 symbols) is this project's own --
  * neither 7z nor libbsc are part of the reference tree -- and is stated in oracle/bfq_codec_ref.c.
  * Any bytes compress (the model adapts to the alphabet it finds); host buffers in and out. */
 uint64_t bfq_stream_bound(uint64_t len);                          /* capacity that always suffices for `len` raw bytes */
@@ -290,6 +299,10 @@ void bfq_prof_reset(bfq_ctx *c);
 int  bfq_prof_count(bfq_ctx *c);
 int  bfq_prof_get(bfq_ctx *c, int idx, char *name, int name_cap, double *total_ms,
                   uint64_t *launches, double *alg_bytes_total);
+/* per-launch durations (ms, launch order, since the last reset) of ONE kernel chosen by its bfq_prof_get index (-1: none):
+ * bfq_prof_trace copies up to cap of them and returns how many there are -- e.g. the radix passes one by one */
+int     bfq_prof_trace_select(bfq_ctx *c, int idx);
+int64_t bfq_prof_trace(bfq_ctx *c, float *ms, uint64_t cap);
 
 uint64_t bfq_workspace_bytes(bfq_ctx *c);      /* current device workspace size */
 const char *bfq_version(void);

@@ -8,17 +8,20 @@
  * segment of 8192 symbols coded on its own so that encoder and decoder run one segment per lane.
  *
  * Line-structured streams (read names) first go through a LINE-DELTA transform when that shrinks them to 3/4 or less:
- *   char magic[8] = "BFQLINE1" | u64 raw_len | u32 R (= 256) | u32 0 | u64 number of lines | one BFQRANS1 container of the
+ *   char magic[8] = "BFQLINE1" | u64 raw_len | u32 R (= 256) | u32 0 | u64 number of lines | one BFQRANS2 container of the
  *   transformed bytes: per line (bytes up to and including its '\n'; the stream must end with one) a record
  *   byte(p + (p >= 10)) + line[p:], p = 0 for every R-th line, else the length of the prefix shared with the line before,
  *   capped at 254 and at the line's length - 1 (the record keeps the line's '\n', and no other byte of it is a '\n').
  * A file may hold several containers of either kind back to back (one per block of a sharded run).
  *
  * Container (little endian):
- *   char  magic[8] = "BFQRANS1"
+ *   char  magic[8] = "BFQRANS2"
  *   u64   raw_len
  *   u32   seg_syms (8192; halved down to 1024 while raw_len / seg_syms < 65536, so that short streams still fill the GPU),
  *         nseg = ceil(raw_len / seg_syms), A (distinct byte values), k (context order), scale_bits (12)
+ *   u64   checksum of the raw bytes (below): the decoder recomputes it from what it decoded and refuses a mismatch --
+ *         7z and bsc, whose place this takes, verify a CRC too; without it payload damage that still parses decodes to
+ *         plausible wrong reads
  *   u8    alphabet[256]          byte value of symbol 0..A-1, ascending; the rest 0
  *   u16   dflt[A]                order-0 row: the model of every context without a row of its own
  *   u8    used[ceil(A^k / 8)]    bit c: context c has a row (it occurs in the sampled segments)
@@ -36,6 +39,9 @@
  * rANS: state x in [2^23, 2^31), symbols coded last to first, bytes emitted low byte first and stored backwards, so the
  * decoder reads forwards: x = le32, then per symbol slot = x & (2^scale - 1), s = symbol with cum[s] <= slot < cum[s] + f[s],
  * x = f[s] * (x >> scale) + slot - cum[s], while x < 2^23: x = x << 8 | next byte.
+ * Checksum: the raw bytes as little-endian 64-bit words w_0, w_1, ... (the last one zero-padded),
+ *   mix(raw_len ^ sum_j mix(w_j + (j + 1) * 0x9E3779B97F4A7C15))  mod 2^64,  mix = the splitmix64 finaliser:
+ * a sum of position-keyed terms, so any order of evaluation (one word per GPU lane) gives the same value.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -49,6 +55,20 @@ static void put32(uint8_t *p, uint32_t v) { p[0] = (uint8_t)v; p[1] = (uint8_t)(
 static void put64(uint8_t *p, uint64_t v) { put32(p, (uint32_t)v); put32(p + 4, (uint32_t)(v >> 32)); }
 static uint32_t get32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 static uint64_t get64(const uint8_t *p) { return (uint64_t)get32(p) | ((uint64_t)get32(p + 4) << 32); }
+
+#define BQC_HDR 44u                                 /* magic, raw_len, five u32, checksum */
+static uint64_t mix64(uint64_t z) { z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31; return z; }
+uint64_t orc_codec_checksum(const uint8_t *in, uint64_t n)
+{
+    uint64_t sum = 0;
+    for (uint64_t j = 0; 8 * j < n; j++) {
+        uint64_t w = 0;
+        const uint64_t m = n - 8 * j < 8 ? n - 8 * j : 8;
+        for (uint64_t b = 0; b < m; b++) w |= (uint64_t)in[8 * j + b] << (8 * b);
+        sum += mix64(w + (j + 1) * 0x9E3779B97F4A7C15ull);
+    }
+    return mix64(n ^ sum);
+}
 
 static uint32_t choose_k(uint32_t A, uint64_t n)
 {
@@ -145,13 +165,14 @@ static int64_t rans_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t
         uint32_t acc = 0;
         for (uint32_t s = 0; s < A; s++) { cum[c * A + s] = (uint16_t)acc; acc += freq[c * A + s]; }
     }
-    const uint64_t hdr = 8 + 8 + 5 * 4 + 256 + 2 * A + (nctx + 7) / 8 + nused * A * 2 + (uint64_t)nseg * 4;
+    const uint64_t hdr = BQC_HDR + 256 + 2 * A + (nctx + 7) / 8 + nused * A * 2 + (uint64_t)nseg * 4;
     int64_t ret = -1;
     if (hdr <= cap) {
         uint8_t *p = out;
-        memcpy(p, "BFQRANS1", 8); p += 8;
+        memcpy(p, "BFQRANS2", 8); p += 8;
         put64(p, n); p += 8;
         put32(p, BQC_SEG); put32(p + 4, nseg); put32(p + 8, A); put32(p + 12, k); put32(p + 16, BQC_SCALE); p += 20;
+        put64(p, orc_codec_checksum(in, n)); p += 8;
         memcpy(p, alphabet, 256); p += 256;
         for (uint32_t s = 0; s < A; s++) { p[0] = (uint8_t)dflt[s]; p[1] = (uint8_t)(dflt[s] >> 8); p += 2; }
         memset(p, 0, (nctx + 7) / 8);
@@ -200,12 +221,12 @@ static int64_t rans_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t
 int64_t orc_codec_member_len(const uint8_t *in, uint64_t len)
 {
     if (len >= 32 && !memcmp(in, "BFQLINE1", 8)) { int64_t r = orc_codec_member_len(in + 32, len - 32); return r < 0 ? -1 : r + 32; }
-    if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
+    if (len < BQC_HDR + 256 || memcmp(in, "BFQRANS2", 8)) return -1;
     const uint32_t nseg = get32(in + 20), A = get32(in + 24), k = get32(in + 28);
     if (A == 0 || A > 256 || k > 8) return -1;
     uint64_t nctx = 1;
     for (uint32_t j = 0; j < k; j++) { nctx *= A; if (nctx > (1u << 22)) return -1; }
-    uint64_t pos = 36 + 256 + 2ull * A;
+    uint64_t pos = BQC_HDR + 256 + 2ull * A;
     if (pos + (nctx + 7) / 8 > len) return -1;
     uint64_t nused = 0;
     for (uint64_t c = 0; c < nctx; c++) nused += (in[pos + (c >> 3)] >> (c & 7)) & 1;
@@ -220,23 +241,23 @@ int64_t orc_codec_member_len(const uint8_t *in, uint64_t len)
 int64_t orc_codec_raw_len(const uint8_t *in, uint64_t len)
 {
     if (len >= 32 && !memcmp(in, "BFQLINE1", 8)) return (int64_t)get64(in + 8);
-    if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
+    if (len < BQC_HDR + 256 || memcmp(in, "BFQRANS2", 8)) return -1;
     return (int64_t)get64(in + 8);
 }
 
 /* returns raw_len, -1 on a malformed container / short `cap` */
 static int64_t rans_decode(const uint8_t *in, uint64_t len, uint8_t *out, uint64_t cap)
 {
-    if (len < 36 + 256 || memcmp(in, "BFQRANS1", 8)) return -1;
+    if (len < BQC_HDR + 256 || memcmp(in, "BFQRANS2", 8)) return -1;
     const uint64_t n = get64(in + 8);
     const uint32_t seg = get32(in + 16), nseg = get32(in + 20), A = get32(in + 24), k = get32(in + 28), scale = get32(in + 32);
     if (n > cap || seg != choose_seg(n) || scale != BQC_SCALE || A == 0 || A > 256 || k > 8 || nseg != (n + seg - 1) / seg) return -1;
-    const uint8_t *alphabet = in + 36;
+    const uint8_t *alphabet = in + BQC_HDR;
     uint64_t nctx = 1;
     for (uint32_t j = 0; j < k; j++) { nctx *= A; if (nctx > (1u << 22)) return -1; }
     const uint64_t top = nctx;
-    if (36 + 256 + 2ull * A + (nctx + 7) / 8 > len) return -1;
-    const uint8_t *dfl = in + 36 + 256;
+    if (BQC_HDR + 256 + 2ull * A + (nctx + 7) / 8 > len) return -1;
+    const uint8_t *dfl = in + BQC_HDR + 256;
     const uint8_t *used = dfl + 2ull * A;
     const uint8_t *rows = used + (nctx + 7) / 8;
     uint16_t *freq = (uint16_t *)calloc(nctx * A, 2), *cum = (uint16_t *)calloc(nctx * A, 2);
@@ -282,6 +303,7 @@ static int64_t rans_decode(const uint8_t *in, uint64_t len, uint8_t *out, uint64
         pay += bytes;
     }
     free(freq); free(cum);
+    if (ret >= 0 && orc_codec_checksum(out, n) != get64(in + 36)) ret = -1;
     return ret;
 }
 

@@ -100,7 +100,7 @@ def ref_binary(M, B):
     return p if os.path.exists(p) else None
 
 
-# ---- stream codec (oracle/bfq_codec_ref.c): the CPU statement of the BFQRANS1 container
+# ---- stream codec (oracle/bfq_codec_ref.c): the CPU statement of the BFQRANS2 container
 def codec_encode(data):
     data = np.ascontiguousarray(np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else data, np.uint8)
     L = lib()
@@ -127,7 +127,7 @@ def codec_decode(blob):
         ml = L.orc_codec_member_len(_p(part), C.c_uint64(len(part)))
         n = L.orc_codec_raw_len(_p(part), C.c_uint64(len(part)))
         if ml < 0 or n < 0:
-            raise RuntimeError("not a BFQRANS1 stream")
+            raise RuntimeError("not a BFQRANS2 stream")
         out = np.empty(max(int(n), 1), np.uint8)
         r = L.orc_codec_decode(_p(part), C.c_uint64(ml), _p(out), C.c_uint64(n))
         if r != n:

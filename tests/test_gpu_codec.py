@@ -57,7 +57,7 @@ def test_job_with_compressed_streams(engine):
     assert z.stats == plain.stats and np.array_equal(z.fastq, plain.fastq)
     for a, b in ((z.dna, plain.dna), (z.qs, plain.qs), (z.hdr, plain.hdr)):
         a = np.asarray(a)
-        assert bytes(a[:8]) in (b"BFQRANS1", b"BFQLINE1") and len(a) < len(b)
+        assert bytes(a[:8]) in (b"BFQRANS2", b"BFQLINE1") and len(a) < len(b)
         assert np.array_equal(np.asarray(engine.stream_decompress(a)), np.asarray(b))
         assert np.array_equal(orc.codec_encode(np.asarray(b)), a)
     # two parts (paired blocks): the containers cover the whole collection
@@ -151,8 +151,8 @@ def test_line_delta_transform(engine):
                                    for i in range(300000)), np.uint8)
     ragged = np.frombuffer(b"".join(b"@" + bytes(rng.integers(97, 100, int(rng.integers(1, 60))).astype(np.uint8)) + b"\n"
                                     for _ in range(20000)), np.uint8)
-    for data, kind in ((c["headers"], b"BFQLINE1"), (names, b"BFQLINE1"), (ragged, None), (c["dna_like"], b"BFQRANS1"),
-                       (np.frombuffer(b"ab\n" * 1000, np.uint8), b"BFQRANS1"), (np.frombuffer(b"@r1\n@r2", np.uint8), b"BFQRANS1"),
+    for data, kind in ((c["headers"], b"BFQLINE1"), (names, b"BFQLINE1"), (ragged, None), (c["dna_like"], b"BFQRANS2"),
+                       (np.frombuffer(b"ab\n" * 1000, np.uint8), b"BFQRANS2"), (np.frombuffer(b"@r1\n@r2", np.uint8), b"BFQRANS2"),
                        (np.frombuffer((b"x" * 20 + b"\n") * 600, np.uint8), b"BFQLINE1")):
         blob = np.asarray(engine.stream_compress(data))
         want = orc.codec_encode(data)
@@ -181,11 +181,25 @@ def test_refuses_damaged_streams(engine):
     bad = blob.copy(); bad[3] ^= 0x20
     with pytest.raises(api.BfqError):
         engine.stream_decompress(bad)
-    flip = blob.copy(); flip[-5] ^= 0xFF                       # payload damage: wrong bytes or a refused stream, never a hang
-    try:
+    # payload damage that still parses: refused by the checksum of the decoded bytes (never wrong bytes, never a hang)
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        flip = blob.copy(); flip[int(rng.integers(len(blob) - 4000, len(blob)))] ^= int(rng.integers(1, 256))
+        with pytest.raises(api.BfqError):
+            engine.stream_decompress(flip)
+    flip = blob.copy(); flip[36] ^= 1                            # the checksum field
+    with pytest.raises(api.BfqError):
         engine.stream_decompress(flip)
-    except api.BfqError:
-        pass
+    # whole segments zeroed (a torn write, a sparse hole inside a .dna payload): k_cdc_decode8's refill must end -- a state
+    # word of 0 followed by zeros used to refill for ever
+    for a, b in ((3000, 500), (9000, 100), (len(blob) // 2, len(blob) // 4)):
+        z = blob.copy(); z[len(blob) - a:len(blob) - b] = 0
+        with pytest.raises(api.BfqError):
+            engine.stream_decompress(z)
+    qs = np.asarray(engine.stream_compress(cases()["smoothed_qs_like"])).copy()     # the generic decoder (> 8 symbols)
+    z = qs.copy(); z[len(qs) - 6000:len(qs) - 200] = 0
+    with pytest.raises(api.BfqError):
+        engine.stream_decompress(z)
 
 
 def test_bsc_front_end(tmp_path):
@@ -199,7 +213,7 @@ def test_bsc_front_end(tmp_path):
     r = subprocess.run([exe, "e", str(f), str(f) + ".bsc", "-T"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout
     blob = (tmp_path / "OUT.fq.qs.bsc").read_bytes()
-    assert blob[:8] == b"BFQRANS1" and len(blob) < len(raw) // 3
+    assert blob[:8] == b"BFQRANS2" and len(blob) < len(raw) // 3
     assert (orc.codec_encode(np.frombuffer(raw, np.uint8)) == np.frombuffer(blob, np.uint8)).all()
     r = subprocess.run([exe, "d", str(f) + ".bsc", str(tmp_path / "back")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
     assert r.returncode == 0, r.stdout

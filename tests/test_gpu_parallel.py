@@ -51,7 +51,7 @@ def test_streams_headers_and_paired(tmp_path):
 
 
 def test_step_5_in_the_sharded_run(orc, tmp_path):
-    """--compress over 2 ranks: `<name>.bsc` = one BFQRANS1 container per block in block order; decoded (CPU statement and
+    """--compress over 2 ranks: `<name>.bsc` = one BFQRANS2 container per block in block order; decoded (CPU statement and
     GPU codec) they are the files of the run without step 5."""
     from bfqzip_amd import api
     f1, f2 = paired_inputs(str(tmp_path))

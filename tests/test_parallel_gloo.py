@@ -69,7 +69,7 @@ def test_output_names_follow_the_reference():
 
 
 def test_sharded_run_with_step_5(orc, tmp_path):
-    """--compress: every block's share of every output as one BFQRANS1 container, the files `<name>.bsc` hold them in block
+    """--compress: every block's share of every output as one BFQRANS2 container, the files `<name>.bsc` hold them in block
     order and decode to what the run without step 5 writes (paired: the mates' shares are coded separately)."""
     eng = util.OracleEngine(orc, m=5)
     f1, f2 = paired_inputs(str(tmp_path))
@@ -80,7 +80,7 @@ def test_sharded_run_with_step_5(orc, tmp_path):
     for o in range(2):
         for kind in ("fastq", "dna", "qs", "hdr"):
             blob = np.frombuffer(open(z[o][kind] + ".bsc", "rb").read(), np.uint8)
-            assert blob[:8].tobytes() == b"BFQRANS1"
+            assert blob[:8].tobytes() == b"BFQRANS2"
             assert orc.codec_decode(blob).tobytes() == open(plain[o][kind], "rb").read(), (o, kind)
             assert not os.path.exists(z[o][kind])
 
