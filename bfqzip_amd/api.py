@@ -25,9 +25,9 @@ class BfqError(RuntimeError):
         self.code = code
 
 
-def make_params(k=16, m=2, v=ord(">"), f=40, t=20, s=ord("#"), M=2, B=0, ext=0, piles=0):
+def make_params(k=16, m=2, v=ord(">"), f=40, t=20, s=ord("#"), M=2, B=0, ext=0, piles=0, ws_cap_mib=0):
     p = _lib.Params()
-    p.K, p.m, p.v, p.f, p.t, p.term, p.M, p.B, p.ext, p.piles = k, m, v, f, t, s, M, B, ext, piles
+    p.K, p.m, p.v, p.f, p.t, p.term, p.M, p.B, p.ext, p.piles, p.ws_cap_mib = k, m, v, f, t, s, M, B, ext, piles, ws_cap_mib
     return p
 
 
@@ -84,10 +84,20 @@ def text_nth_newline(buf, k):
     return int(_lib.lib().bfq_text_nth_newline(_ptr(a) if len(a) else None, len(a), k))
 
 
+def file_put(fd, data, offset, threads=0):
+    """The bytes of `data` (uint8 array / bytes) into the open file `fd` at `offset` (bfq_file_put: several threads, no GPU)."""
+    a = _u8(data)
+    if len(a):
+        rc = _lib.lib().bfq_file_put(fd, offset, _ptr(a), len(a), threads)
+        if rc:
+            raise BfqError(rc, "bfq_file_put")
+
+
 class HostText:
     """Host-side text helpers of libbfqhip.so (no GPU involved)."""
     text_line_counts = staticmethod(text_line_counts)
     text_nth_newline = staticmethod(text_nth_newline)
+    file_put = staticmethod(file_put)
 
 
 class Engine:
@@ -287,15 +297,23 @@ class Engine:
         self._ck(self.L.bfq_glob_run_pile(self.h, t8.data_ptr(), q8.data_ptr(), n, s, s2, sym.data_ptr(), qual.data_ptr(), C.byref(st)))
         return st.as_dict()
 
-    def glob_finish(self, dna, qs, keep_headers=False, fastq=True, streams=False, hdr=False, text_len=0, nparts=1):
-        """dna / qs: this block's line streams (torch uint8, device).  Returns a JobResult like fastq_job."""
+    def glob_finish(self, dna, qs, keep_headers=False, fastq=True, streams=False, hdr=False, text_len=0, nparts=1, out=None):
+        """dna / qs: this block's line streams (torch uint8, device).  Returns a JobResult like fastq_job.  `out`: reusable
+        output arrays under 'fastq', 'dna', 'qs', 'hdr' (e.g. PinnedBuffer.array: direct DMA), used when large enough."""
         J = _lib.FastqJob()
         J.nparts = 0; J.keep_headers = 1 if keep_headers else 0
         sl = int(dna.numel())
-        bf = np.empty(text_len + 32, np.uint8) if fastq else None
-        bd = np.empty(sl + 16, np.uint8) if streams else None
-        bq = np.empty(sl + 16, np.uint8) if streams else None
-        bh = np.empty(text_len + 16, np.uint8) if hdr else None
+        out = out or {}
+
+        def buf(key, want, size):
+            if not want:
+                return None
+            b = out.get(key)
+            return b if (b is not None and len(b) >= size) else np.empty(size, np.uint8)
+        bf = buf("fastq", fastq, text_len + 32)
+        bd = buf("dna", streams, sl + 16)
+        bq = buf("qs", streams, sl + 16)
+        bh = buf("hdr", hdr, text_len + 16)
         if bf is not None:
             J.out_fastq = bf.ctypes.data; J.cap_fastq = len(bf)
         if bd is not None:

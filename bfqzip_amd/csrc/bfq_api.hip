@@ -27,16 +27,82 @@ const char *const BFQ_KERNEL_NAMES[K_NUM] = {
 static thread_local std::string g_createErr;
 
 // ---------------------------------------------------------------- context plumbing
+// The arena can also be built from physically contiguous chunks mapped into one address range (HIP's virtual memory
+// management: BFQ_WS_VMM=<chunk MiB>): what the 512 write streams of a radix pass cost depends on how the range is backed
+// (placement experiments).
+void bfq_ctx::wsFree()
+{
+    if (!ws) return;
+    (void)hipStreamSynchronize(stream);
+    if (wsVmmChunk) {
+        (void)hipMemUnmap(ws, wsCap);
+        for (auto h : wsHandles) (void)hipMemRelease((hipMemGenericAllocationHandle_t)h);
+        wsHandles.clear();
+        (void)hipMemAddressFree(ws, wsCap);
+        wsVmmChunk = 0;
+    } else (void)hipFree(ws);
+    ws = nullptr; wsCap = 0; wsTop = 0;
+}
+static hipError_t ws_alloc_vmm(bfq_ctx *c, size_t bytes, size_t chunk, char **out, size_t *got)
+{
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof prop);
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+    if (e != hipSuccess) return e;
+    if (chunk < gran) chunk = gran;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t total = (bytes + chunk - 1) / chunk * chunk;
+    void *va = nullptr;
+    e = hipMemAddressReserve(&va, total, chunk, nullptr, 0);
+    if (e != hipSuccess) return e;
+    std::vector<void *> hs;
+    for (size_t o = 0; o < total && e == hipSuccess; o += chunk) {
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, chunk, &prop, 0);
+        if (e == hipSuccess) { hs.push_back((void *)h); e = hipMemMap((char *)va + o, chunk, 0, h, 0); }
+    }
+    if (e == hipSuccess) {
+        hipMemAccessDesc d;
+        memset(&d, 0, sizeof d);
+        d.location.type = hipMemLocationTypeDevice; d.location.id = c->device; d.flags = hipMemAccessFlagsProtReadWrite;
+        e = hipMemSetAccess(va, total, &d, 1);
+    }
+    if (e != hipSuccess) {
+        (void)hipMemUnmap(va, total);
+        for (auto h : hs) (void)hipMemRelease((hipMemGenericAllocationHandle_t)h);
+        (void)hipMemAddressFree(va, total);
+        return e;
+    }
+    c->wsHandles = hs; c->wsVmmChunk = chunk;
+    *out = (char *)va; *got = total;
+    return hipSuccess;
+}
+
 void bfq_ctx::reserve(size_t bytes)
 {
     bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
-    if (bytes > wsCap) {
-        if (ws) { HIP_CHECK(hipStreamSynchronize(stream)); HIP_CHECK(hipFree(ws)); ws = nullptr; wsCap = 0; }
+    if (wsLimit() && bytes > wsLimit()) {
+        char b[200];
+        snprintf(b, sizeof b, "device workspace of %.1f GiB is above the cap of %.1f GiB (bfq_params.ws_cap_mib / BFQ_WS_CAP)", bytes / 1073741824.0, wsLimit() / 1073741824.0);
+        throw BfqError{BFQ_E_NOMEM, b};
+    }
+    if (bytes > wsCap || (wsLimit() && wsCap > wsLimit())) {    // (an arena from before the cap was set goes back)
+        wsFree();
         struct timespec t0, t1;
         clock_gettime(CLOCK_MONOTONIC, &t0);
         hipError_t e = hipErrorOutOfMemory;
         bool contig = false;
-        if (env.wsContig) { e = hipExtMallocWithFlags((void **)&ws, bytes, hipDeviceMallocContiguous); contig = e == hipSuccess; if (!contig) (void)hipGetLastError(); }
+        if (env.wsVmmMib) {
+            size_t got = 0;
+            e = ws_alloc_vmm(this, bytes, (size_t)env.wsVmmMib << 20, &ws, &got);
+            if (e == hipSuccess) bytes = got; else { (void)hipGetLastError(); ws = nullptr; }
+            if (bfq_env().trace) fprintf(stderr, "[bfq] workspace: VMM chunks of %d MiB %s\n", env.wsVmmMib, e == hipSuccess ? "mapped" : "refused");
+        }
+        if (e != hipSuccess && env.wsContig) { e = hipExtMallocWithFlags((void **)&ws, bytes, hipDeviceMallocContiguous); contig = e == hipSuccess; if (!contig) (void)hipGetLastError(); }
         if (e != hipSuccess) e = hipMalloc((void **)&ws, bytes);
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if (bfq_env().trace && env.wsContig) fprintf(stderr, "[bfq] workspace: contiguous allocation %s\n", contig ? "granted" : "refused");
@@ -55,8 +121,7 @@ void bfq_ctx::reserve(size_t bytes)
 }
 void bfq_ctx::dropWorkspace()
 {
-    HIP_CHECK(hipStreamSynchronize(stream));
-    if (ws) { HIP_CHECK(hipFree(ws)); ws = nullptr; wsCap = 0; wsTop = 0; }
+    wsFree();
     d_bwt = d_qual = nullptr; d_lcp = nullptr; d_gcnt = nullptr;
 }
 void *bfq_ctx::allocBytes(size_t bytes)
@@ -212,7 +277,7 @@ extern "C" void bfq_destroy(bfq_ctx *c)
     for (auto e : c->evPool) (void)hipEventDestroy(e);
     c->ioFree();
     if (c->d_text) (void)hipFree(c->d_text);
-    if (c->ws) (void)hipFree(c->ws);
+    c->wsFree();
     if (c->d_cnt) (void)hipFree(c->d_cnt);
     if (c->d_powtab) (void)hipFree(c->d_powtab);
     if (c->d_qthr) (void)hipFree(c->d_qthr);
@@ -331,20 +396,48 @@ static size_t ws_need_given(u64 n, u64 N, u64 extra)
     return need;
 }
 
+// the capped mode (steps_capped): T8 + Q8 + the two line streams (4 n), packed text, block counts, one pile of `pile` rows
+// (pile-local eBWT / QS / LCP 4 B, sort records 24 B, flags and cluster tables ~4 B per row)
+static size_t ws_need_capped(u64 n, u64 N, u64 pile, u64 extra)
+{
+    size_t need = 0;
+    need += 4 * (n + 512) + 8 * (n / 21 + 8);
+    need += 2 * 6 * 12 * (n / 32768 + 2) + 16 * (N + 64);
+    if (pile) need += 32 * (pile + 256) + 256 * 12 * (ceil_div(pile + 1, bfq_radix_block_elems(pile)) + 8200) + (pile / 32768 + 4096) * 64;
+    need += extra + (96u << 20);
+    return need;
+}
+
 // Workspace for a call that runs step 1 on n rows: in one piece (ws_need) or pile by pile (bfq_params.piles: 1 always,
 // 0 = when the one-piece workspace cannot be had, -1 never; the environment variable BFQ_PILES=0/1 overrides).
-static void reserve_step1(bfq_ctx *c, u64 n, u64 N, u64 extra)
+static void reserve_step1(bfq_ctx *c, u64 n, u64 N, u64 extra, bool allowCapped = true)
 {
     int mode = c->P.piles;
     if (c->env.piles) mode = c->env.piles;
+    if (mode == 2 && !allowCapped) mode = 1;                     // the caller wants the eBWT arrays: the capped mode has none
     const u64 cap = n / 10 * 3 + (1u << 20);                     // a DNA pile holds about a quarter of the suffixes; larger ones are split again
-    c->piles = false;
+    c->piles = false; c->capped = false;
     if (mode <= 0) {
-        try { c->reserve(ws_need(n, N, extra + c->env.abPad + (c->env.abSwap ? 12 * (n + 256) : 0))); return; }
+        try { c->reserve(ws_need(n, N, extra + c->env.abPad + ((c->env.abSwap || c->env.abOrder[0]) ? 12 * (n + 256) : 0))); return; }
         catch (const BfqError &e) { if (mode < 0 || e.code != BFQ_E_NOMEM) throw; }
     }
-    c->reserve(bfq_ws_need_piles(n, N, cap, extra));
-    c->piles = true;
+    if (mode != 2) {
+        try { c->reserve(bfq_ws_need_piles(n, N, cap, extra)); c->piles = true; return; }
+        catch (const BfqError &e) { if (e.code != BFQ_E_NOMEM || !c->wsLimit() || !allowCapped) throw; }
+    }
+    // Below 13 n bytes (a workspace cap): the capped mode.  Its arena holds the terminated text (T8, Q8, packed text), the
+    // line streams the edits go to, and ONE two-symbol pile at a time -- as large a pile as the cap leaves room for.
+    const size_t base = ws_need_capped(n, N, 0, extra), lim = c->wsLimit();
+    u64 rows = !lim ? n / 4 + (1u << 20) : lim > base + (128u << 20) ? (u64)((lim - base - (128u << 20)) / 32) : 0;   // (no cap: bfq_params.piles = 2 asked for the mode)
+    if (rows > n / 4 + (1u << 20)) rows = n / 4 + (1u << 20);
+    if (lim && rows < n / 64 + 4096) {
+        char b[220];
+        snprintf(b, sizeof b, "workspace cap of %.1f GiB too small for %llu rows: the capped mode needs %.1f GiB + 32 bytes per row of its largest two-symbol pile",
+                 lim / 1073741824.0, (unsigned long long)n, base / 1073741824.0);
+        throw BfqError{BFQ_E_NOMEM, b};
+    }
+    c->reserve(ws_need_capped(n, N, rows, extra));
+    c->capped = true; c->cappedPileRows = rows;
 }
 
 // ---------------------------------------------------------------- step 1
@@ -366,13 +459,26 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     u64 *text3 = c->alloc<u64>(nwords);
     SortRec A, B;
     const bool abSwap = c->env.abSwap && !c->keepRecs;  // placement experiment: B below A
+    size_t mKeep = 0, mB = 0;
+    if (c->env.abOrder[0] && !c->keepRecs) {            // placement experiment: the four arrays in any order (0 A.w12, 1 A.w0, 2 B.w0, 3 B.w12)
+        for (int k = 0; k < 4; k++) {
+            switch (c->env.abOrder[k]) {
+            case '0': A.w12 = c->alloc<u64>(n + 16); break;
+            case '1': A.w0 = c->alloc<u32>(n + 16); break;
+            case '2': B.w0 = c->alloc<u32>(n + 16); break;
+            default: B.w12 = c->alloc<u64>(n + 16); break;
+            }
+        }
+        mKeep = mB = c->mark();
+    } else {
     if (abSwap) { B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16); }
     A.w12 = c->alloc<u64>(n + 16);
-    const size_t mKeep = c->mark();                     // position mode keeps the text and the records' (w1, w2) words
+    mKeep = c->mark();                                  // position mode keeps the text and the records' (w1, w2) words
     A.w0 = c->alloc<u32>(n + 16);
-    size_t mB = c->mark();
+    mB = c->mark();
     if (c->env.abPad) (void)c->allocBytes((size_t)c->env.abPad);
     if (!abSwap) { B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16); }
+    }
     if (bfq_env().trace) fprintf(stderr, "[bfq] sort buffers: A.w12 %p A.w0 %p B.w0 %p B.w12 %p (arena %p)\n", (void *)A.w12, (void *)A.w0, (void *)B.w0, (void *)B.w12, (void *)c->ws);
     u8 *T8 = (u8 *)A.w0, *Q8 = (u8 *)A.w12;             // dead before the sort's first scatter
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
@@ -407,15 +513,16 @@ static void count_lengths(bfq_ctx *c, const RankIndex &R, u64 *d_roff, u32 *lens
 // so != nullptr: the outputs are the line streams OUT.fq.dna / OUT.fq.qs (d_out_bases / d_out_quals hold total + N bytes);
 // with pinned host destinations the inversion runs in read-range chunks and every finished chunk is copied to the host on
 // a second stream while the next one is walked.
-struct StreamOut { u8 *h_dna, *h_qs; };
+struct StreamOut { u8 *h_dna, *h_qs; bool packed = false; };   // packed: the reads back to back (read i at roff[i]) instead of line streams
 static void invert_lines(bfq_ctx *c, const RankIndex &R, const u64 *d_roff, u8 *d_dna, u8 *d_qs, const StreamOut *so)
 {
     const u64 N = c->N;
+    const bool lines = !so->packed;
     const bool pinned = (!so->h_dna || bfq_is_pinned(so->h_dna)) && (!so->h_qs || bfq_is_pinned(so->h_qs));
     const int C = (pinned && N >= (1u << 16) && !c->env.noOverlap) ? 8 : 1;
     if (C == 1) {
-        bfq_invert(c, R, N, d_roff, c->P.B, d_dna, d_qs, 0, ~0ull, true);
-        const u64 sl = (c->n - N) + N;
+        bfq_invert(c, R, N, d_roff, c->P.B, d_dna, d_qs, 0, ~0ull, lines);
+        const u64 sl = (c->n - N) + (lines ? N : 0);
         if (so->h_dna) bfq_download(c, so->h_dna, d_dna, sl);
         if (so->h_qs) bfq_download(c, so->h_qs, d_qs, sl);
         return;
@@ -428,10 +535,10 @@ static void invert_lines(bfq_ctx *c, const RankIndex &R, const u64 *d_roff, u8 *
     hipEvent_t ev[8];
     for (int j = 0; j < C; j++) {
         HIP_CHECK(hipEventCreateWithFlags(&ev[j], hipEventDisableTiming));
-        bfq_invert(c, R, N, d_roff, c->P.B, d_dna, d_qs, first[j], first[j + 1] - first[j], true);
+        bfq_invert(c, R, N, d_roff, c->P.B, d_dna, d_qs, first[j], first[j + 1] - first[j], lines);
         HIP_CHECK(hipEventRecord(ev[j], c->stream));
         HIP_CHECK(hipStreamWaitEvent(c->copyStream, ev[j], 0));
-        const u64 b0 = off[j] + first[j], b1 = off[j + 1] + first[j + 1];
+        const u64 b0 = off[j] + (lines ? first[j] : 0), b1 = off[j + 1] + (lines ? first[j + 1] : 0);
         if (so->h_dna) HIP_CHECK(hipMemcpyAsync(so->h_dna + b0, d_dna + b0, b1 - b0, hipMemcpyDeviceToHost, c->copyStream));
         if (so->h_qs) HIP_CHECK(hipMemcpyAsync(so->h_qs + b0, d_qs + b0, b1 - b0, hipMemcpyDeviceToHost, c->copyStream));
     }
@@ -478,7 +585,18 @@ static void steps234_device(bfq_ctx *c, u64 *d_roff, u8 *d_out_bases, u8 *d_out_
         if (eo->lineQs) { StreamOut none{nullptr, nullptr}; invert_lines(c, R, d_roff, eo->lineDna, eo->lineQs, &none); }
         return;
     }
-    if (so) { invert_lines(c, R, d_roff, d_out_bases, d_out_quals, so); return; }
+    if (so) {
+        invert_lines(c, R, d_roff, d_out_bases, d_out_quals, so);
+        if (guessed) {
+            c->fetchCounters();
+            if (c->h_cnt.errInvert) {                              // not all of one length after all: count, then walk again
+                HIP_CHECK(hipMemsetAsync(&c->d_cnt->errInvert, 0, sizeof(u64), c->stream));
+                count_lengths(c, R, d_roff, lens);
+                invert_lines(c, R, d_roff, d_out_bases, d_out_quals, so);
+            }
+        }
+        return;
+    }
     bfq_invert(c, R, N, d_roff, c->P.B, d_out_bases, d_out_quals);
     if (guessed) {
         c->fetchCounters();
@@ -531,6 +649,65 @@ static void steps34_positions(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, 
     if (N) KLAUNCH(c, K_MISC, 4.0 * (double)(n - N), k_lines_strip, bfq_grid(N, 16), 256, (const u8 *)dna, (const u8 *)qs, d_roff, N, d_out_bases, d_out_quals);
 }
 
+// ---- the whole path under a workspace cap (the counterpart of bfq_ext's pile files, bfq_ext.cpp:190-348, and
+// of its lock-step inversion, decode.cpp:499-966): what bounds a block is the eBWT-sized state -- 24 B of sort records, the
+// 8-byte LF entry, the eBWT / QS / LCP arrays.  None of it is needed all at once.  The suffixes are cut into piles by their
+// first TWO symbols (clusters never cross such a pile when K >= 2: the LCP at its border is at most 1); a pile is sorted,
+// refined and analysed on its own, every row still knows the text position of its suffix (the sort payload), so edits go
+// straight to that position of the output line streams and the one place that needs bwt[LF(row)] (bfq_int.cpp:545-560)
+// reads the packed text two symbols back.  No eBWT is ever materialised, nothing is inverted: the line streams ARE the
+// reads.  Resident: 4.4 n bytes + one pile.  dna / qs: n bytes each (read i at roff[i] + i, then '\n').
+static void steps_capped(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 *d_roff, u64 N, u64 total, u8 *dna, u8 *qs)
+{
+    const u64 n = total + N;
+    if (n >= (1ull << BFQ_POS_BITS)) throw BfqError{BFQ_E_ARG, "collection too large (2^37 rows)"};
+    c->n = n; c->N = N;
+    c->d_bwt = c->d_qual = nullptr; c->d_lcp = nullptr; c->d_gcnt = nullptr;     // no eBWT exists in this mode
+    if (!n) return;
+    if (c->P.K < 1) throw BfqError{BFQ_E_NOMEM, "the capped mode needs -k >= 1 (with -k 0 every row is in one cluster): raise the workspace cap"};
+    const size_t m0 = c->mark();
+    const u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
+    u64 *text3 = c->alloc<u64>(nwords);
+    u8 *T8 = c->alloc<u8>(n + 64), *Q8 = c->alloc<u8>(n + 64);
+    bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
+    if (N) KLAUNCH(c, K_MISC, 4.0 * (double)(n - N), k_lines_init, bfq_grid(N, 16), 256, d_bases, d_quals, d_roff, N, c->P.B, dna, qs);
+    u64 cnt[36];
+    bfq_pile_pair_counts(c, T8, n, cnt);                         // synchronises
+    c->fetchCounters();
+    if (c->h_cnt.errSymbol || c->h_cnt.errTooLong) { c->release(m0); return; }   // reported by the caller's check
+    const bool two = c->P.K >= 2;                                // -k 1: clusters may cross two-symbol piles: first-symbol piles
+    for (u32 s = 1; s <= 5; s++) {
+        for (u32 s2 = two ? 1u : 7u; s2 <= (two ? 5u : 7u); s2++) {
+            u64 rows = 0;
+            if (two) rows = cnt[6 * s + s2]; else for (int q = 0; q < 6; q++) rows += cnt[6 * s + q];
+            if (!rows) continue;
+            if (rows > c->cappedPileRows) {
+                char b[220];
+                snprintf(b, sizeof b, "pile '%c%c' holds %llu rows, the workspace cap leaves room for %llu: raise bfq_params.ws_cap_mib / BFQ_WS_CAP",
+                         "#ACGNT"[s], two ? "#ACGNT"[s2] : '*', (unsigned long long)rows, (unsigned long long)c->cappedPileRows);
+                throw BfqError{BFQ_E_NOMEM, b};
+            }
+            const size_t mp = c->mark();
+            PileRows pr;
+            if (bfq_env().trace) fprintf(stderr, "[bfq capped] pile %c%c: %llu rows, arena %zu of %zu used\n", "#ACGNT"[s], two ? "#ACGNT"[s2] : '*', (unsigned long long)rows, c->wsTop, c->wsCap);
+            const u64 m = bfq_run_one_pile(c, T8, Q8, text3, n, s, s2, c->P.term & 0xFF, &pr);
+            if (bfq_env().trace) { c->sync(); fprintf(stderr, "[bfq capped]   sorted + refined\n"); }
+            if (m) {
+                u8 *in = c->alloc<u8>(m + 64);
+                bfq_lcp_flags(c, pr.lcp, m, c->P.K, in);
+                ClusterPos pm{pr.w12, text3, dna, qs, c->P.B};
+                RankIndex none{nullptr, m};
+                bfq_clusters(c, none, pr.bwt, pr.qs, in, m, &pm);
+            }
+            c->sync();                                           // the pile's arrays go back to the arena
+            if (bfq_env().trace) fprintf(stderr, "[bfq capped]   clusters done\n");
+            c->release(mp);
+        }
+    }
+    c->release(m0);
+}
+
+
 extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const uint8_t *d_quals,
                                     const uint64_t *d_read_off, uint64_t N, uint64_t total, uint8_t *d_out_bases,
                                     uint8_t *d_out_quals, bfq_stats *st)
@@ -539,6 +716,17 @@ extern "C" int bfq_run_reads_device(bfq_ctx *c, const uint8_t *d_bases, const ui
         if (st) memset(st, 0, sizeof *st);
         reserve_step1(c, total + N, N, 0);
         c->zeroCounters();
+        if (c->capped) {
+            const u64 n = total + N;
+            u8 *dna = c->alloc<u8>(n + 64), *qs = c->alloc<u8>(n + 64);
+            steps_capped(c, d_bases, d_quals, (const u64 *)d_read_off, N, total, dna, qs);
+            if (N) KLAUNCH(c, K_MISC, 4.0 * (double)total, k_lines_strip, bfq_grid(N, 16), 256, (const u8 *)dna, (const u8 *)qs, (const u64 *)d_read_off, N, d_out_bases, d_out_quals);
+            c->fetchCounters();
+            c->profCollect();
+            check_counters(c);
+            fill_stats(c, st);
+            return;
+        }
         const bool posMode = !c->piles && c->env.posMode;
         c->keepRecs = posMode;
         bfq_step1_device(c, d_bases, d_quals, (const u64 *)d_read_off, N, total, c->P.term, st);
@@ -559,7 +747,7 @@ extern "C" int bfq_run_reads(bfq_ctx *c, const uint8_t *h_bases, const uint8_t *
         if (st) memset(st, 0, sizeof *st);
         if (!h_read_off) throw BfqError{BFQ_E_ARG, "null read offsets"};
         u64 total = h_read_off[N];
-        reserve_step1(c, total + N, N, 4 * (total + 256) + 8 * (N + 64));
+        reserve_step1(c, total + N, N, 6 * (total + 256) + 10 * (N + 64));   // (+ 2 n: the capped mode's line streams beside its outputs)
         c->zeroCounters();
         u8 *db = c->alloc<u8>(total + 64), *dq = c->alloc<u8>(total + 64);
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
@@ -567,8 +755,14 @@ extern "C" int bfq_run_reads(bfq_ctx *c, const uint8_t *h_bases, const uint8_t *
         bfq_upload(c, db, h_bases, total);
         bfq_upload(c, dq, h_quals, total);
         bfq_upload(c, dr, h_read_off, 8 * (N + 1));
-        bfq_step1_device(c, db, dq, dr, N, total, c->P.term, st);
-        steps234_device(c, dr, ob, oq);
+        if (c->capped) {
+            u8 *dna = c->alloc<u8>(total + N + 64), *qs = c->alloc<u8>(total + N + 64);
+            steps_capped(c, db, dq, dr, N, total, dna, qs);
+            if (N) KLAUNCH(c, K_MISC, 4.0 * (double)total, k_lines_strip, bfq_grid(N, 16), 256, (const u8 *)dna, (const u8 *)qs, (const u64 *)dr, N, ob, oq);
+        } else {
+            bfq_step1_device(c, db, dq, dr, N, total, c->P.term, st);
+            steps234_device(c, dr, ob, oq);
+        }
         bfq_download(c, h_out_bases, ob, total);
         bfq_download(c, h_out_quals, oq, total);
         c->fetchCounters();
@@ -584,7 +778,7 @@ extern "C" int bfq_build_ebwt(bfq_ctx *c, const uint8_t *h_bases, const uint8_t 
     return guarded(c, [&] {
         if (!h_read_off) throw BfqError{BFQ_E_ARG, "null read offsets"};
         u64 total = h_read_off[N], n = total + N;
-        reserve_step1(c, n, N, 2 * (total + 256) + 8 * (N + 64));
+        reserve_step1(c, n, N, 2 * (total + 256) + 8 * (N + 64), false);
         c->zeroCounters();
         u8 *db = c->alloc<u8>(total + 64), *dq = c->alloc<u8>(total + 64);
         u64 *dr = c->alloc<u64>(N + 1);
@@ -641,8 +835,10 @@ __global__ __launch_bounds__(256) void k_count_byte(const u8 *__restrict__ a, u6
 // The eBWT and its qualities are uploaded into the context's text buffer (outside the arena), the terminators are
 // counted there, and only then is the arena sized.
 struct SmoothOut { u8 *ob, *oq; u64 *roff; u64 N, total; };
+// hostOut != nullptr: the reads go to these host arrays while the inversion is still running (read-range chunks, each copied
+// out on the copy stream behind its walk); the caller then downloads nothing but the offsets
 static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostRef h_lcp, int lcp_bytes,
-                               uint64_t n, size_t extraWs, bfq_stats *st, SmoothOut *res)
+                               uint64_t n, size_t extraWs, bfq_stats *st, SmoothOut *res, const StreamOut *hostOut = nullptr)
 {
     {
         if (st) memset(st, 0, sizeof *st);
@@ -666,9 +862,17 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
         // the qualities are not needed before the LF table is built: a pageable / file source is staged by a helper thread
         // while this thread goes on (the LCP deduction from the BWT alone takes longer than the upload)
         BfqAsyncUpload *qsUp = nullptr;
-        const bool qsAsync = !haveLcp && n >= (64u << 20) && !(h_bwtqs.ptr && bfq_is_pinned(h_bwtqs.ptr)) && !c->env.noOverlap;
-        if (qsAsync) qsUp = bfq_upload_begin(c, in_qs, h_bwtqs, n);
+        const bool qsPinned = h_bwtqs.ptr && bfq_is_pinned(h_bwtqs.ptr);
+        const bool qsAsync = !haveLcp && n >= (64u << 20) && !c->env.noOverlap;
+        hipEvent_t qsEv = nullptr;
+        if (qsAsync && qsPinned) {                                 // one DMA on the copy stream, beside the kernels of the LCP deduction
+            if (!c->copyStream) HIP_CHECK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&qsEv, hipEventDisableTiming));
+            HIP_CHECK(hipMemcpyAsync(in_qs, h_bwtqs.ptr, n, hipMemcpyHostToDevice, c->copyStream));
+            HIP_CHECK(hipEventRecord(qsEv, c->copyStream));
+        } else if (qsAsync) qsUp = bfq_upload_begin(c, in_qs, h_bwtqs, n);
         else bfq_upload(c, in_qs, h_bwtqs, n);
+        struct EvGuard { hipEvent_t &e; bfq_ctx *c; ~EvGuard() { if (e) { (void)hipStreamSynchronize(c->copyStream); (void)hipEventDestroy(e); e = nullptr; } } } evGuard{qsEv, c};
         struct Join { BfqAsyncUpload *u; ~Join() { if (u) { try { bfq_upload_join(u); } catch (...) {} } } } joinGuard{qsUp};
         u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
         u64 *d_roff = c->alloc<u64>(N + 1);
@@ -693,8 +897,9 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
             c->gcntTerm = c->P.term & 0xFF;
         }
         if (qsUp) { bfq_phase("read_h2d"); joinGuard.u = nullptr; bfq_upload_join(qsUp); }
+        if (qsEv) HIP_CHECK(hipStreamWaitEvent(c->stream, qsEv, 0));
         bfq_phase("gpu");
-        steps234_device(c, d_roff, ob, oq, lens);
+        steps234_device(c, d_roff, ob, oq, lens, hostOut);
         res->ob = ob; res->oq = oq; res->roff = d_roff; res->N = N; res->total = total;
     }
 }
@@ -705,9 +910,8 @@ extern "C" int bfq_smooth_invert(bfq_ctx *c, const uint8_t *h_bwt, const uint8_t
 {
     return guarded(c, [&] {
         SmoothOut r;
-        smooth_invert_core(c, HostRef::mem(h_bwt), HostRef::mem(h_bwtqs), HostRef::mem(h_lcp), lcp_bytes, n, 0, st, &r);
-        bfq_download(c, h_out_bases, r.ob, r.total);
-        bfq_download(c, h_out_quals, r.oq, r.total);
+        const StreamOut ho{h_out_bases, h_out_quals, true};
+        smooth_invert_core(c, HostRef::mem(h_bwt), HostRef::mem(h_bwtqs), HostRef::mem(h_lcp), lcp_bytes, n, 0, st, &r, &ho);
         bfq_download(c, h_out_read_off, r.roff, 8 * (r.N + 1));
         c->fetchCounters();
         c->profCollect();
@@ -747,7 +951,7 @@ static bool src_ends_with_newline(const TextSrc &t)
     if (pread(t.ref.fd, &b, 1, (off_t)(t.ref.off + t.len - 1)) != 1) throw BfqError{BFQ_E_IO, "cannot read the input file"};
     return b == (u8)'\n';
 }
-static u8 *fastq_upload_and_reserve(bfq_ctx *c, const TextSrc *parts, int nparts, std::vector<u64> &pstart, size_t extraWs = 0)
+static u8 *fastq_upload_and_reserve(bfq_ctx *c, const TextSrc *parts, int nparts, std::vector<u64> &pstart, size_t extraWs = 0, bool allowCapped = true)
 {
     pstart.assign(nparts + 1, 0);
     std::vector<u8> addNl(nparts, 0);
@@ -773,7 +977,7 @@ static u8 *fastq_upload_and_reserve(bfq_ctx *c, const TextSrc *parts, int nparts
     u64 N = nlines / 4 + 1;
     u64 nb = len / 2 + 1;                                       // rows <= bytes / 2
     bfq_phase("alloc");
-    reserve_step1(c, nb, N, 3 * (len + 4096) + 128 * (N + 64) + 8 * (nlines + 64) + extraWs);
+    reserve_step1(c, nb, N, 3 * (len + 4096) + 128 * (N + 64) + 8 * (nlines + 64) + extraWs, allowCapped);
     bfq_phase("gpu");
     return d_fq;
 }
@@ -797,7 +1001,7 @@ static void fastq_build_ebwt_core(bfq_ctx *c, TextSrc text, int term_out, HostRe
 {
     if (!lcp.null() && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
     std::vector<u64> ps;
-    u8 *d_fq = fastq_upload_and_reserve(c, &text, 1, ps);
+    u8 *d_fq = fastq_upload_and_reserve(c, &text, 1, ps, 0, false);
     c->zeroCounters();
     DevFastq fq;
     bfq_fastq_parse(c, d_fq, ps[1], &fq);
@@ -1039,9 +1243,11 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         const bool ebwtDomain = J->compress_streams == 2 || J->compress_streams == 3;   // rows of the edited eBWT instead of reads
         const bool qsByRead = J->compress_streams == 3;            // ... but the qualities in read order (they keep their along-the-read correlation)
         if (ebwtDomain && (!J->out_dna || !J->out_qs || J->out_fastq)) throw BfqError{BFQ_E_ARG, "compress_streams = 2 gives out_dna and out_qs (no FASTQ text)"};
-        const bool lines = J->out_dna || J->out_qs;               // the inversion writes the line streams itself
+        if (c->capped && ebwtDomain) throw BfqError{BFQ_E_NOMEM, "eBWT-domain containers need the LF table: above the workspace cap"};
+        const bool lines = J->out_dna || J->out_qs || c->capped;  // the inversion writes the line streams itself (the capped mode knows nothing else)
         const u64 sl = fq.total + fq.N;
-        if (lines && sl > J->cap_stream) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
+        const bool wantLines = J->out_dna || J->out_qs;
+        if (wantLines && sl > J->cap_stream) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
         u8 *ob = c->alloc<u8>((lines ? sl : fq.total) + 64), *oq = c->alloc<u8>((lines ? sl : fq.total) + 64);
         u8 *op = ebwtDomain ? c->alloc<u8>(sl + 64) : nullptr;    // eBWT domain: the replaced rows' original symbols
         u8 *lineDna = qsByRead ? c->alloc<u8>(sl + 64) : nullptr, *lineQs = qsByRead ? c->alloc<u8>(sl + 64) : nullptr;
@@ -1049,7 +1255,7 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         u64 *d_pidx = c->alloc<u64>(np + 1), *d_pick = c->alloc<u64>(4 * (np + 1));
         bfq_fastq_part_index(c, &fq, ps.data(), np, d_pidx);
         std::vector<u64> hp(4 * (np + 1), 0);
-        bool pickF = false, pickS = false, pickH = false;
+        bool pickF = false, pickS = false, pickH = false, hdrOnCopyStream = false;
         HIP_CHECK(hipMemcpyAsync(hp.data(), d_pidx, 8 * (np + 1), hipMemcpyDeviceToHost, c->stream));
         if (J->out_hdr) {                                      // the header stream needs only the parsed text: out before the sort starts
             u8 *d_hdr = nullptr;
@@ -1066,7 +1272,17 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
                 c->release(mz);
             } else {
                 if (hl > J->cap_hdr) throw BfqError{BFQ_E_ARG, "stream buffer too small (the input length is always enough)"};
-                bfq_download(c, J->out_hdr, d_hdr, hl);
+                if (hl >= (1u << 20) && bfq_is_pinned(J->out_hdr) && !c->env.noOverlap) {
+                    // a pinned destination: the copy rides the copy stream beside the sort instead of in front of it
+                    if (!c->copyStream) HIP_CHECK(hipStreamCreateWithFlags(&c->copyStream, hipStreamNonBlocking));
+                    hipEvent_t ev;
+                    HIP_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+                    HIP_CHECK(hipEventRecord(ev, c->stream));
+                    HIP_CHECK(hipStreamWaitEvent(c->copyStream, ev, 0));
+                    HIP_CHECK(hipMemcpyAsync(J->out_hdr, d_hdr, hl, hipMemcpyDeviceToHost, c->copyStream));
+                    (void)hipEventDestroy(ev);
+                    hdrOnCopyStream = true;
+                } else bfq_download(c, J->out_hdr, d_hdr, hl);
                 J->hdr_bytes = hl;
             }
             bfq_pick_u64(c, hOff, d_pidx, np + 1, 0, d_pick + 3 * (np + 1));
@@ -1074,14 +1290,20 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
         }
         if (wantStreams) { bfq_pick_u64(c, fq.roff, d_pidx, np + 1, 1, d_pick + 2 * (np + 1)); pickS = true; }   // roff[i] + i
         size_t m = c->mark();
-        bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
         StreamOut so{cz ? nullptr : J->out_dna, cz ? nullptr : J->out_qs};
-        EbwtOut eo{ob, oq, op, lineDna, lineQs};                                       // (n = total + N rows: the line-stream buffers have exactly that size)
-        steps234_device(c, fq.roff, ob, oq, nullptr, lines ? &so : nullptr, ebwtDomain ? &eo : nullptr);
-        if (lines) { J->stream_len = sl; if (!cz) { J->dna_bytes = J->out_dna ? sl : 0; J->qs_bytes = J->out_qs ? sl : 0; } }
+        if (c->capped) {
+            steps_capped(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, ob, oq);
+            if (so.h_dna) bfq_download(c, so.h_dna, ob, sl);
+            if (so.h_qs) bfq_download(c, so.h_qs, oq, sl);
+        } else {
+            bfq_step1_device(c, fq.bases, fq.quals, fq.roff, fq.N, fq.total, c->P.term, st);
+            EbwtOut eo{ob, oq, op, lineDna, lineQs};                                   // (n = total + N rows: the line-stream buffers have exactly that size)
+            steps234_device(c, fq.roff, ob, oq, nullptr, lines ? &so : nullptr, ebwtDomain ? &eo : nullptr);
+        }
+        if (J->out_dna || J->out_qs) { J->stream_len = sl; if (!cz) { J->dna_bytes = J->out_dna ? sl : 0; J->qs_bytes = J->out_qs ? sl : 0; } }
         c->release(m);                                         // the formatted text may reuse the pipeline's space:
         c->d_bwt = c->d_qual = nullptr; c->d_lcp = nullptr; c->d_gcnt = nullptr;   // the eBWT is gone (bfq_fetch_ebwt refuses)
-        if (lines && cz) {                                     // step 5 on the device, in the space the pipeline has left
+        if (wantLines && cz) {                                 // step 5 on the device, in the space the pipeline has left
             const size_t mz = c->mark();
             const u64 bound = bfq_codec_bound(sl) < J->cap_stream ? bfq_codec_bound(sl) : J->cap_stream;
             u8 *d_z = c->alloc<u8>(bound + 16);
@@ -1115,6 +1337,7 @@ extern "C" int bfq_fastq_run_job(bfq_ctx *c, bfq_fastq_job *J, bfq_stats *st)
             pickF = true;
         }
         HIP_CHECK(hipMemcpyAsync(hp.data() + (np + 1), d_pick + (np + 1), 8 * 3 * (np + 1), hipMemcpyDeviceToHost, c->stream));
+        if (hdrOnCopyStream) HIP_CHECK(hipStreamSynchronize(c->copyStream));
         c->fetchCounters();
         c->profCollect();
         check_counters(c);

@@ -73,6 +73,9 @@ struct bfq_ctx {
     char *ws = nullptr;
     size_t wsCap = 0, wsTop = 0;
     void reserve(size_t bytes);
+    void wsFree();
+    size_t wsVmmChunk = 0;              // != 0: the arena is VMM chunks of this size mapped into one range (experiment)
+    std::vector<void *> wsHandles;
     void dropWorkspace();           // frees the arena now (one-shot tools: lets the driver scrub it while outputs are written)
     void *allocBytes(size_t bytes);
     template <class T> T *alloc(size_t count) { return (T *)allocBytes(count * sizeof(T)); }
@@ -91,6 +94,9 @@ struct bfq_ctx {
     int gcntTerm = -1;              // terminator byte those counts were taken with
     u64 n = 0, N = 0;
     bool piles = false;             // step 1 runs pile by pile (k_piles.hip): set by the reservation of the current call
+    bool capped = false;            // the whole path in position mode, one two-symbol pile at a time (workspace cap): set likewise
+    u64 cappedPileRows = 0;         // ... and the rows of the largest pile its arena has room for
+    size_t wsLimit() const { return env.wsCap ? (size_t)env.wsCap : (size_t)(P.ws_cap_mib > 0 ? P.ws_cap_mib : 0) << 20; }
     bool keepRecs = false;          // step 1 leaves the packed text and the sorted records' (w1, w2) words in the arena (position mode)
     const u64 *d_w12 = nullptr, *d_text3 = nullptr;
     size_t keepMark = 0;

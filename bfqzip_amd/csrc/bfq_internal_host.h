@@ -8,7 +8,7 @@
 // A context keeps its own copy, refreshed by bfq_create() and bfq_set_params() only (test knobs change between calls).
 struct BfqEnv {
     bool trace = false;             // BFQ_TRACE: phase timeline, transfer rates, workspace allocations on stderr
-    int piles = 0;                  // BFQ_PILES=1/0: step 1 pile by pile always / never (overrides bfq_params.piles); unset: 0
+    int piles = 0;                  // BFQ_PILES=1/0/2: step 1 pile by pile always / never, 2: the capped mode always (overrides bfq_params.piles); unset: 0
     bool pilesSplit = false;        // BFQ_PILES_SPLIT: every pile once more by its second symbol (test knob)
     bool noOverlap = false;         // BFQ_NO_OVERLAP: inversion and device -> host copies one after the other
     bool noLengthGuess = false;     // BFQ_NO_LENGTH_GUESS: always count read lengths by LF walks
@@ -22,8 +22,11 @@ struct BfqEnv {
     int fakeDevices = 0;            // BFQ_FAKE_DEVICES=n: pretend n GPUs (slot k -> device k mod the real count): lease tests on one GPU
     bool lease = true;              // BFQ_LEASE=0: no lease files (the caller places the tools itself)
     std::string leaseDir;           // BFQ_LEASE_DIR: where the lock files live (default /dev/shm, else /tmp)
+    bool rsPerm = false;            // BFQ_RS_PERM=1: the radix passes take their blocks spread by a coprime stride instead of in order (placement experiments: no effect)
+    int wsVmmMib = 0;               // BFQ_WS_VMM=<MiB>: the workspace as physically contiguous chunks of that size mapped into one range (hipMemCreate / hipMemMap)
     bool wsContig = false;          // BFQ_WS_CONTIG=1: ask for a physically contiguous workspace (hipDeviceMallocContiguous), plain hipMalloc if refused
     unsigned long long abPad = 0;   // BFQ_AB_PAD: bytes left free between the two sort-record buffers (placement experiments)
+    char abOrder[8] = {0};          // BFQ_AB_ORDER=<permutation of 0123>: the order of A.w12, A.w0, B.w0, B.w12 in the arena (placement experiments)
     bool abSwap = false;            // BFQ_AB_SWAP=1: the second record buffer below the first (placement experiments)
     bool noOutmap = false;          // BFQ_NO_OUTMAP: the tools write their outputs with pwrite instead of through a mapping (test knob)
     int invertNt = 1;               // BFQ_INVERT_NT=0: plain instead of nontemporal LF-table loads in k_invert

@@ -204,6 +204,8 @@ void bfq_refine_huge(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp,
         bfq_ctx *c; char *ws; size_t cap, top; char *side;
         ~Restore() { if (side) { (void)hipStreamSynchronize(c->stream); (void)hipFree(side); c->ws = ws; c->wsCap = cap; c->wsTop = top; } }
     } restore{c, ws0, cap0, top0, side};
+    if (bfq_env().trace) fprintf(stderr, "[bfq huge] %llu segments, %llu rows, longest %llu; slots %llu%s\n", (unsigned long long)nh, (unsigned long long)hc[1],
+                                 (unsigned long long)maxLen, (unsigned long long)cap, side ? " (side buffer)" : "");
     if (cap > (1ull << 31)) cap = 1ull << 31;          // slot numbers and sub-segment ids are 32-bit sort keys
     if (c->env.hugeCap && c->env.hugeCap < cap) cap = c->env.hugeCap;   // BFQ_HUGE_CAP, test hook: exercise batching and the oversize route on small inputs
     std::vector<u64> overS, overL;

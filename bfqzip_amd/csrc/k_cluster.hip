@@ -549,6 +549,8 @@ void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual,
     a.powtab = c->d_powtab; a.qthr = c->d_qthr; a.qthrLo = c->qthrLo; a.qthrN = c->qthrN;
     a.cnt = c->d_cnt;
     size_t mk = c->mark();
+    // the list of long clusters is per call (pile by pile there are several calls between two resets of the counters)
+    HIP_CHECK(hipMemsetAsync(&c->d_cnt->bigClusters, 0, sizeof(u64), c->stream));
     a.bigStart = c->alloc<u64>(n / CL_BIG + 2);
     a.big = c->alloc<BigState>(n / CL_BIG + 2);
     a.firstOut = c->alloc<u16>(n / CL_WROWS + 8);

@@ -63,7 +63,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const T *__restrict__
 // DW = which word carries the digit of this pass (0: w0, 1: w1)
 template <int DW>
 __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in, SortRec out, u64 n, int shift,
-                                                              const u64 *__restrict__ blockOff, u64 nblocks, u32 tilesPerBlock)
+                                                              const u64 *__restrict__ blockOff, u64 nblocks, u32 tilesPerBlock, u64 blockMul)
 {
     __shared__ u64 stage[RS_TILE];          // w0, then the (w1,w2) pair of the records
     __shared__ u8 dig[RS_TILE];             // digit of every tile-sorted slot
@@ -74,10 +74,15 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
 
     const u32 tid = threadIdx.x, lane = bfq_lane(), w = tid >> 6;
     const u64 ltmask = bfq_lanemask_lt();
-    if (tid < 256) gbase[tid] = blockOff[(u64)tid * nblocks + blockIdx.x];
+    // Which block this workgroup sorts: in order, or (blockMul != 0, BFQ_RS_PERM=1) spread by a stride coprime to the block
+    // count, so that the ~1000 resident workgroups write all over every digit's bucket instead of into 256 windows of a few
+    // MB that move in lock-step.  Built to test whether such windows explain why a pass costs 26 or 34 ms depending on where
+    // the buffers lie: they do not -- the times are the same either way (profiles/r3/placement.md).
+    const u64 blk = blockMul ? ((u64)blockIdx.x * blockMul) % nblocks : (u64)blockIdx.x;
+    if (tid < 256) gbase[tid] = blockOff[(u64)tid * nblocks + blk];
 
     for (u32 t = 0; t < tilesPerBlock; t++) {
-        u64 tbase = ((u64)blockIdx.x * tilesPerBlock + t) * RS_TILE;
+        u64 tbase = (blk * tilesPerBlock + t) * RS_TILE;
         if (tbase >= n) break;                                   // uniform
         u32 cnt = (n - tbase < (u64)RS_TILE) ? (u32)(n - tbase) : (u32)RS_TILE;
 
@@ -190,6 +195,13 @@ SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes, c
     u32 *hist = c->alloc<u32>(256 * nb);
     u64 *off = c->alloc<u64>(256 * nb);
     SortRec out = tmp;
+    // stride of the block permutation: near the golden section of the block count, coprime to it (0: blocks in order)
+    u64 mul = 0;
+    if (c->env.rsPerm && nb >= 64) {
+        auto gcd = [](u64 a, u64 b) { while (b) { const u64 t = a % b; a = b; b = t; } return a; };
+        mul = (u64)((double)nb * 0.6180339887) | 1ull;
+        while (gcd(mul, nb) != 1) mul += 2;
+    }
     for (int pass = 0; pass < passes; pass++) {
         const int dw = pass == 0 ? 1 : 0;
         const int shift = pass == 0 ? 24 : 8 * (pass - 1);
@@ -200,9 +212,9 @@ SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes, c
             KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist<u32>, nb, RS_THREADS, (const u32 *)in.w0, n, shift, hist, nb, be);
         bfq_exscan_u32(c, have ? hist0 : hist, off, 256 * nb, nullptr);
         if (dw)
-            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb);
+            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb, mul);
         else
-            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<0>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb);
+            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<0>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb, mul);
         SortRec t = in; in = out; out = t;
     }
     c->release(m);

@@ -95,8 +95,14 @@ class Comm:
             t.copy_(h)
 
 
-def pwrite_all(fd, data, offset):
-    """os.pwrite until everything is written (one call moves at most 0x7ffff000 bytes on Linux)."""
+def pwrite_all(fd, data, offset, host=None):
+    """`data` into the open file at `offset`: through the library's threaded writer (bfq_file_put: fallocate + shared
+    mapping, several threads -- a 9.5 GB output takes a Python os.pwrite 1.6 s) when the engine's host helpers offer it,
+    else os.pwrite until everything is written (one call moves at most 0x7ffff000 bytes on Linux)."""
+    put = getattr(host, "file_put", None) if host is not None else None
+    if put is not None and len(data) >= (1 << 20):
+        put(fd, data, offset)
+        return
     mv = memoryview(data).cast("B")
     done = 0
     while done < len(mv):
@@ -175,8 +181,15 @@ def output_names(inputs, out, paired):
 KINDS = ("fastq", "dna", "qs", "hdr")
 
 
+def _pinned_outputs(kinds, cap):
+    """Page-locked output buffers of `cap` bytes for the wanted kinds (direct DMA instead of the staging pipeline)."""
+    from . import api
+    pins = {k: api.PinnedBuffer(cap) for k in kinds}
+    return pins, {k: p.array for k, p in pins.items()}
+
+
 def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fastq=True, want_streams=False,
-              want_hdr=False, out_bufs=None, log=None, compress=False):
+              want_hdr=False, out_bufs=None, log=None, compress=False, pinned=False):
     """The whole multi-GPU job.  eng: Engine-like (fastq_job, text_line_counts/text_nth_newline via `eng.host`).
     Returns per-rank totals {"blocks", "reads", "bases", "stats"} (stats summed over this rank's blocks).
     compress: step 5 too (BFQzip.py:253-275) -- every block's share of every output goes through the stream codec
@@ -196,10 +209,16 @@ def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fas
             for k in kinds:
                 open(names[o][k], "wb").close()
     comm.barrier()
-    fds = {(o, k): os.open(names[o][k], os.O_WRONLY) for o in range(nout) for k in kinds}
+    fds = {(o, k): os.open(names[o][k], os.O_RDWR) for o in range(nout) for k in kinds}       # (read too: the writer maps the file)
     cursor = np.zeros((nout, 4), np.int64)                           # next free byte of every output file
     tot = {"blocks": 0, "reads": 0, "bases": 0, "stats": {}}
     out_bufs = out_bufs if out_bufs is not None else {}
+    pins = None
+    if pinned and not out_bufs and nblocks:
+        # sized from the line index: the largest block's bytes (+ its mate's) bound every one of its outputs
+        big = max((blocks[0][k][1] - blocks[0][k][0]) + ((blocks[1][k][1] - blocks[1][k][0]) if paired and k < len(blocks[1]) else 0)
+                  for k in range(nblocks))
+        pins, out_bufs = _pinned_outputs(kinds, big + 5 * 2 + 64)
     rounds = (nblocks + comm.world - 1) // comm.world
     for rd in range(rounds):
         k = rd * comm.world + comm.rank
@@ -242,10 +261,13 @@ def run_files(eng, comm, inputs, t, names, paired=False, headers=False, want_fas
                     if kind in kinds and sizes[o, ki]:
                         lo = cut[kind][o]
                         piece = blobs[(o, kind)] if compress else data[kind][lo:lo + int(sizes[o, ki])]
-                        pwrite_all(fds[(o, kind)], piece, int(cursor[o, ki] + before[o, ki]))
+                        pwrite_all(fds[(o, kind)], piece, int(cursor[o, ki] + before[o, ki]), host)
         cursor += allsz.sum(axis=0)[:nout]
     for fd in fds.values():
         os.close(fd)
+    if pins:
+        for pb in pins.values():
+            pb.free()
     comm.barrier()
     return tot
 
@@ -263,7 +285,8 @@ def deal_piles(counts, world):
     return mine
 
 
-def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_streams=False, want_hdr=False, log=None):
+def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_streams=False, want_hdr=False, log=None, out_bufs=None,
+               pinned=False):
     """ONE collection over all ranks with the result of the unsharded run (k_global.hip): every rank parses its share of the
     file(s), the terminated text is exchanged, the two-symbol piles of the global eBWT are dealt to the ranks, the edits are
     combined with one all-reduce, and every rank writes its own reads.  Two input files (paired end) form ONE collection --
@@ -331,8 +354,9 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
         counts = eng.glob_pile_counts(t8, n)
         mine = deal_piles(counts, W)[r]
         eng.glob_init_out(t8, q8, n, sym, qual)
-        osym, oqual = sym.clone(), qual.clone()
-        tsync()                                                      # the clones are read before the piles edit sym / qual
+        if W > 1:
+            osym, oqual = sym.clone(), qual.clone()
+            tsync()                                                  # the clones are read before the piles edit sym / qual
         for s, s2 in mine:
             st = eng.glob_run_pile(t8, q8, n, s, s2, sym, qual)
             for key, v in st.items():
@@ -342,16 +366,26 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
                 log(f"pile {'#ACGNT'[s]}{'#ACGNT'[s2]}: {st['n_rows']} rows, {st['num_clust']} clusters")
         del t8, q8
         lap("piles")
-        sym ^= osym; qual ^= oqual                                   # what this rank's piles changed (zero elsewhere)
-        comm.all_reduce_sum_(sym); comm.all_reduce_sum_(qual)
         segs = [(int(base[f][r]), int(base[f][r]) + myrows[f]) for f in range(nf)]
-        dna = torch.cat([osym[a:b] ^ sym[a:b] for a, b in segs]); qs = torch.cat([oqual[a:b] ^ qual[a:b] for a, b in segs])
-        del sym, qual, osym, oqual
+        if W > 1:
+            sym ^= osym; qual ^= oqual                               # what this rank's piles changed (zero elsewhere)
+            comm.all_reduce_sum_(sym); comm.all_reduce_sum_(qual)
+            dna = torch.cat([osym[a:b] ^ sym[a:b] for a, b in segs]); qs = torch.cat([oqual[a:b] ^ qual[a:b] for a, b in segs])
+            del osym, oqual
+        elif nf == 1:                                                # one rank, one file: the edited streams are the result as they are
+            dna, qs = sym[segs[0][0]:segs[0][1]], qual[segs[0][0]:segs[0][1]]
+        else:
+            dna = torch.cat([sym[a:b] for a, b in segs]); qs = torch.cat([qual[a:b] for a, b in segs])
+        del sym, qual
         lap("delta all-reduce")
     else:
         dna = torch.empty(0, dtype=torch.uint8, device=dev); qs = dna.clone()
     tsync()
-    res = eng.glob_finish(dna, qs, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr, text_len=int(tlen), nparts=nf)
+    pins = None
+    if pinned and not out_bufs:
+        pins, out_bufs = _pinned_outputs([k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w], int(tlen) + 64)
+    res = eng.glob_finish(dna, qs, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr, text_len=int(tlen), nparts=nf,
+                          **({"out": out_bufs} if out_bufs else {}))
     # outputs at their final offsets: output f = the shares of part f of all ranks, in rank order
     kinds = [k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w]
     if comm.rank == 0:
@@ -371,10 +405,14 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
     for f in range(nf):
         for ki, kind in enumerate(KINDS):
             if kind in kinds:
-                fd = os.open(names[f][kind], os.O_WRONLY)
+                fd = os.open(names[f][kind], os.O_RDWR)
                 if sizes[f, ki]:
-                    pwrite_all(fd, data[kind][cut[kind][f]:cut[kind][f + 1]], int(before[f, ki]))
+                    pwrite_all(fd, data[kind][cut[kind][f]:cut[kind][f + 1]], int(before[f, ki]), host)
                 os.close(fd)
+    if pins:
+        del res, data
+        for pb in pins.values():
+            pb.free()
     comm.barrier()
     lap("format+write")
     keys = sorted(tot["stats"]) if tot["stats"] else ["num_clust", "num_clust_discarded", "num_clust_amb_discarded", "num_clust_mod",
@@ -443,19 +481,14 @@ def main(argv=None):
     eng = api.Engine(local, **par)
     names = output_names(a.input, a.out, a.paired)
     streams = a.m2 or a.m3
-    bufs = {}
-    if a.pinned:
-        cap = max(os.path.getsize(p) for p in a.input) * (2 if a.paired else 1) // max(1, a.threads) * 2 + (1 << 20)
-        pins = {k: api.PinnedBuffer(cap) for k in (["fastq"] if not a.streams_only else []) + (["dna", "qs"] if streams else []) + (["hdr"] if a.m3 else [])}
-        bufs = {k: p.array for k, p in pins.items()}
     log = (lambda m: print(f"[rank {comm.rank}] {m}", flush=True)) if a.v else None
     if a.glob:
         tot = run_global(eng, comm, a.input[:2 if a.paired else 1], names, headers=a.headers, want_fastq=not (streams and a.streams_only),
-                         want_streams=streams, want_hdr=a.m3, log=log)
+                         want_streams=streams, want_hdr=a.m3, log=log, pinned=a.pinned)
     else:
         tot = run_files(eng, comm, a.input, a.threads, names, paired=a.paired, headers=a.headers,
-                        want_fastq=not (streams and a.streams_only), want_streams=streams, want_hdr=a.m3, out_bufs=bufs, log=log,
-                        compress=a.compress and not a.m0)
+                        want_fastq=not (streams and a.streams_only), want_streams=streams, want_hdr=a.m3, log=log,
+                        compress=a.compress and not a.m0, pinned=a.pinned)
     if a.v:
         print(f"[rank {comm.rank}] {tot}", flush=True)
     eng.close()

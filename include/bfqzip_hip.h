@@ -47,8 +47,13 @@ typedef struct bfq_params {
     int32_t B;      /* 1 = Illumina 8-level binning               default 0         */
     int32_t ext;    /* 1 = bfq_ext arithmetic for M=3 (bfq_ext.cpp:496)             */
     int32_t piles;  /* step 1 pile by pile (first-symbol piles as in bfq_ext.cpp:190-348; 13 n bytes of workspace
-                       instead of 28.6 n): 1 always, 0 when the one-piece workspace cannot be had, -1 never     */
-    int32_t reserved[6];
+                       instead of 28.6 n): 1 always, 0 when the one-piece workspace cannot be had, -1 never;
+                       2: the capped mode always (see ws_cap_mib)                                                */
+    int32_t ws_cap_mib; /* upper bound of the device workspace in MiB, 0 = none ($BFQ_WS_CAP in bytes, suffixes K/M/G, overrides it).
+                       What a block needs: 28.6 n bytes in one piece, 13 n pile by pile; below that the capped mode runs it in
+                       ~8 n: two-symbol piles one at a time, edits written to the text position of every row, no eBWT-sized
+                       array, no LF table, no inversion -- same bytes out, about twice the time              */
+    int32_t reserved[5];
 } bfq_params;
 
 /* Counters printed by bfq_int.cpp:1004-1019. */
@@ -234,6 +239,11 @@ void  bfq_host_free(void *p);
  * number of '\n' in bytes [i*chunk, (i+1)*chunk), computed by `threads` threads (0: default);
  * bfq_text_nth_newline = offset of the k-th (0-based) '\n' of the range or -1.  Pure host functions (no GPU). */
 int     bfq_text_count_lines(const uint8_t *h_text, uint64_t len, uint64_t chunk, uint64_t *counts, int threads);
+/* a host buffer into a file at an offset by several threads (fallocate + shared mapping; pwrite when the file cannot be
+ * mapped): how the multi-GPU driver puts every block's outputs at their final place of the shared output files
+ * (BFQzip_parallel.py:137-179 merges with `cat`).  fd must be open for reading and writing; the file grows as needed and is
+ * never shrunk, so several processes may fill different ranges of one file.  threads 0: by the CPU budget.  Host only. */
+int     bfq_file_put(int fd, uint64_t offset, const void *src, uint64_t len, int threads);
 int64_t bfq_text_nth_newline(const uint8_t *h_text, uint64_t len, uint64_t k);
 
 /* Device-resident eBWT of the last bfq_run_reads*() / bfq_build_ebwt() call

@@ -13,9 +13,13 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(world, args, tmp, timeout=900):
-    """`python -m torch.distributed.run --nproc-per-node world -m bfqzip_amd.parallel ...` over gloo (one GPU)."""
-    env = dict(os.environ, BFQ_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+def _launch(world, args, tmp, timeout=900, backend="gloo"):
+    """`python -m torch.distributed.run --nproc-per-node world -m bfqzip_amd.parallel ...` over gloo (one GPU);
+    backend=None: the driver's own default (nccl = RCCL, one GPU per rank)."""
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    env.pop("BFQ_BACKEND", None)
+    if backend:
+        env["BFQ_BACKEND"] = backend
     port = 29700 + (os.getpid() * 11 + len(" ".join(args))) % 2000
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), "-m", "bfqzip_amd.parallel"] + args
@@ -182,3 +186,29 @@ def test_global_mode_paired(tmp_path):
             for o in range(2):
                 for k in want[o]:
                     assert open(names[o][k], "rb").read() == want[o][k], (world, o, k)
+
+
+def _gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()                             # counting does not initialise the GPU
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs: the RCCL branches of parallel.py (one rank per GPU)")
+def test_two_gpus_over_rccl(tmp_path):
+    """The default backend (nccl = RCCL over xGMI), one GPU per rank: the sharded run, the paired run and the global mode
+    (broadcasts of the text, all-reduce of the deltas on uint8 device tensors) reproduce the reference md5s.  Skipped on the
+    one-GPU test boxes; there the same code runs over gloo (tests above)."""
+    out = str(tmp_path / "OUT")
+    _launch(2, [EXAMPLE, "-o", out, "-t", "2", "-0"], str(tmp_path), backend=None)
+    assert md5file(out + ".fastq") == MD5[2]
+    _launch(2, [EXAMPLE, "-o", out, "-t", "8", "-0"], str(tmp_path), backend=None)
+    assert md5file(out + ".fastq") == MD5[8]
+    f1, f2 = paired_inputs(str(tmp_path))
+    _launch(2, [f1, f2, "-p", "-o", out, "-t", "2"], str(tmp_path), backend=None)
+    assert md5file(out + "_1.fastq") == MD5_P1 and md5file(out + "_2.fastq") == MD5_P2
+    g = str(tmp_path / "G")
+    _launch(2, [EXAMPLE, "-o", g, "--global", "-0"], str(tmp_path), backend=None)
+    assert md5file(g + ".fastq") == "29866da058baf8e382927c0023e8ab12"                  # the reference's UNSHARDED run (SURVEY App. B)

@@ -193,6 +193,72 @@ def test_pile_mode(engine, orc, monkeypatch):
     engine.set_params()
 
 
+def test_capped_mode(engine, orc):
+    """The whole path under a workspace cap (bfq_params.ws_cap_mib / piles = 2): two-symbol piles one at a
+    time, position-mode clusters, no eBWT, no LF table, no inversion -- the same reads and statistics as the oracle in
+    every smoothing mode, on variable-length / duplicate / N / empty reads, on low-complexity reads (huge segments and
+    clusters inside one pile), through the host-array call and through the FASTQ job (text, streams, headers); -k 1 runs
+    on first-symbol piles, -k 0 is refused; a 2 M-read block under a cap that rules out both other modes equals its
+    uncapped run."""
+    from bfqzip_amd import fastq as fq
+
+    def cases():
+        for M in range(4):
+            sp = api.synth_spec(3000, 50, seed=400 + M, coverage=25)
+            yield api.synth_host(sp) + (dict(M=M, B=M & 1, m=5),)
+        yield api.synth_host(api.synth_spec(4000, 20, Lmax=70, seed=5, coverage=40, err_ppm=20000, n_ppm=15000, snp_every=97, dsnp_every=131)) + (dict(m=5),)
+        rng = np.random.default_rng(78)
+        for it in range(12):
+            b, q, r = util.random_reads(rng, int(rng.integers(1, 300)), 0 if it % 4 == 0 else 1, int(rng.integers(1, 60)))
+            yield b, q, r, dict(M=int(rng.integers(0, 4)), B=int(rng.integers(0, 2)), k=int(rng.choice([1, 2, 3, 5, 16])), m=int(rng.choice([2, 3, 5])))
+        yield _low_complexity(np.random.default_rng(7)) + (dict(m=5, M=1, B=1),)
+        A = lambda s: np.frombuffer(s, np.uint8)
+        yield A(b"ACGTN"), A(b"IIII#"), np.array([0, 5], np.uint64), dict(m=2, k=2)
+        yield A(b""), A(b""), np.array([0, 0, 0], np.uint64), dict(m=2, k=2)              # only empty reads
+    two = 0
+    for ci, (b, q, r, par) in enumerate(cases()):
+        full = dict(k=16, m=2, v=ord(">"), f=40, t=20, M=2, B=0); full.update(par)
+        print(f"capped case {ci}: {len(r) - 1} reads, {len(b)} bases, {par}", flush=True)
+        p = orc.params(K=full["k"], m=full["m"], v=full["v"], f=full["f"], t=full["t"], M=full["M"], B=full["B"])
+        ob, oq, ost = orc.run_reads(b, q, r, p)
+        engine.set_params(piles=2, **full)
+        gb, gq, gst = engine.run_reads(b, q, r)
+        assert np.array_equal(gb, ob) and np.array_equal(gq, oq), par
+        for k in ost:
+            assert ost[k] == gst[k], (k, par)
+        two += ost["num_clust_mod"]
+        hdrs = [b"@r%d some text" % i for i in range(len(r) - 1)]
+        text = fq.format_fastq(b, q, r, hdrs)
+        res = engine.fastq_job([text], keep_headers=True, fastq=True, streams=True, hdr=True)
+        assert np.asarray(res.fastq).tobytes() == fq.format_fastq(ob, oq, r, hdrs)
+        assert np.asarray(res.dna).tobytes() == fq.format_lines(ob, r) and np.asarray(res.qs).tobytes() == fq.format_lines(oq, r)
+        assert np.asarray(res.hdr).tobytes() == b"".join(h + b"\n" for h in hdrs)
+        only = engine.fastq_job([text], keep_headers=False, fastq=True, streams=False)
+        assert np.asarray(only.fastq).tobytes() == fq.format_fastq(ob, oq, r)
+    assert two > 0
+    b, q, r = api.synth_host(api.synth_spec(2000, 40, seed=9))
+    engine.set_params(piles=2, k=0)
+    with pytest.raises(api.BfqError):
+        engine.run_reads(b, q, r)
+    # a block whose one-piece (7 GB) and pile-by-pile (3.9 GB) workspaces are above the cap: the cap selects the mode
+    sp = api.synth_spec(2_000_000, 100, seed=12)
+    b, q, r = api.synth_host(sp)
+    engine.set_params(m=5, M=1, B=1)
+    fb, fq_, fst = engine.run_reads(b, q, r)
+    engine.set_params(m=5, M=1, B=1, ws_cap_mib=3000)
+    cb, cq, cst = engine.run_reads(b, q, r)
+    assert engine.workspace_bytes() <= 3000 << 20
+    assert np.array_equal(cb, fb) and np.array_equal(cq, fq_)
+    assert {k: cst[k] for k in cst if k != "n_big_segments"} == {k: fst[k] for k in fst if k != "n_big_segments"}
+    with pytest.raises(api.BfqError) as e:                                # the eBWT arrays themselves do not fit under it
+        engine.build_ebwt(b, q, r)
+    assert "cap" in str(e.value)
+    engine.set_params(m=5, ws_cap_mib=300)                               # and a cap nothing fits under is an error, not a crash
+    with pytest.raises(api.BfqError):
+        engine.run_reads(b, q, r)
+    engine.set_params()
+
+
 def test_position_mode(engine, orc, monkeypatch):
     """The device-resident fused path without LF table and walks (BFQ_POSMODE=1: k_cluster writes its edits to the text
     position every row's sort record carries): same reads and statistics as the oracle -- all smoothing modes with and without
@@ -301,7 +367,8 @@ def test_full_size_properties(engine):
       4. M=1 (configs[4]'s smoothing): same base edits and same smoothed positions as 2. (the decision tree does not
          depend on M), qualities differ only there;
       5. bfq_int mode (LCP deduced from the eBWT alone) on the 4.53 G-row eBWT of run 2: same reads as run 2;
-      2b. step 1 pile by pile: same reads and statistics as run 2."""
+      2b. step 1 pile by pile: same reads and statistics as run 2;
+      2c. the capped mode under a 40 GiB workspace cap: same reads and statistics as run 2."""
     torch = pytest.importorskip("torch")
     free, total = torch.cuda.mem_get_info()
     if free < 200 * 2**30:
@@ -347,6 +414,15 @@ def test_full_size_properties(engine):
     engine.set_params(k=16, m=5, M=2, B=0, v=ord(">"), piles=1)
     stp = run(); torch.cuda.synchronize()
     assert {k: stp[k] for k in st if k != "n_big_segments"} == {k: st[k] for k in st if k != "n_big_segments"}
+    assert torch.equal(ob, ob2) and torch.equal(oq, oq2)
+    # 2c. the same block under a 40 GiB workspace cap (capped mode: 4.4 n bytes + one two-symbol pile): the same reads
+    import time as _time
+    engine.set_params(k=16, m=5, M=2, B=0, v=ord(">"), ws_cap_mib=40 * 1024)
+    stc = run(); torch.cuda.synchronize()
+    t0 = _time.perf_counter(); stc = run(); torch.cuda.synchronize(); dtc = _time.perf_counter() - t0
+    print(f"capped mode, 30 M x 150 under 40 GiB: workspace {engine.workspace_bytes() / 2**30:.1f} GiB, {dtc * 1e3:.0f} ms per block")
+    assert engine.workspace_bytes() <= 40 * 2**30
+    assert {k: stc[k] for k in st if k != "n_big_segments"} == {k: st[k] for k in st if k != "n_big_segments"}
     assert torch.equal(ob, ob2) and torch.equal(oq, oq2)
     # 3. B = 1
     engine.set_params(k=16, m=5, M=2, B=1, v=ord(">"))

@@ -179,3 +179,38 @@ def test_phase_report_line(tmp_path):
     d = json.loads(line[0][len("[bfq phases] "):])
     assert list(d)[:2] == ["tool", "exec_to_main"] and list(d)[2:] == ["start", "gpu", "total"]
     assert 0.08 <= d["start"] <= 0.5 and 0.08 <= d["gpu"] <= 0.5 and d["total"] >= d["start"] + d["gpu"] and d["exec_to_main"] >= 0
+
+
+def test_file_put_places_ranges_of_one_file(tmp_path):
+    """bfq_file_put: every rank writes its byte range of a shared output file (bfqzip_amd/parallel.py; the reference merges
+    with `cat`, BFQzip_parallel.py:174-177).  Ranges in any order, unaligned offsets, several threads, a file that grows
+    and is never shrunk; a descriptor that cannot be mapped falls back to pwrite."""
+    rng = np.random.default_rng(1)
+    data = rng.integers(0, 256, 9_000_001, dtype=np.uint8)
+    cuts = [0, 3, 4097, 1_000_000, 5_000_001, len(data)]
+    path = str(tmp_path / "out.bin")
+    open(path, "wb").close()
+    order = [3, 0, 4, 2, 1]
+    for k in order:                                                   # the last range first: the file grows, nothing already there is lost
+        fd = os.open(path, os.O_RDWR)
+        api.file_put(fd, data[cuts[k]:cuts[k + 1]], cuts[k], threads=1 + k % 3)
+        os.close(fd)
+    assert np.array_equal(np.fromfile(path, np.uint8), data)
+    api.file_put(os.open(path, os.O_RDWR), data[:0], 0)               # nothing to write
+    # two processes at once, disjoint halves
+    import subprocess, sys
+    half = len(data) // 2
+    np.save(str(tmp_path / "d.npy"), data)
+    p2 = str(tmp_path / "two.bin")
+    open(p2, "wb").close()
+    code = ("import sys, os, numpy as np; sys.path.insert(0, %r)\nfrom bfqzip_amd import api\n"
+            "d = np.load(sys.argv[1]); a, b = int(sys.argv[3]), int(sys.argv[4])\n"
+            "fd = os.open(sys.argv[2], os.O_RDWR); api.file_put(fd, d[a:b], a); os.close(fd)\n") % ROOT
+    ps = [subprocess.Popen([sys.executable, "-c", code, str(tmp_path / "d.npy"), p2, str(a), str(b)]) for a, b in ((half, len(data)), (0, half))]
+    assert all(p.wait(timeout=300) == 0 for p in ps)
+    assert np.array_equal(np.fromfile(p2, np.uint8), data)
+    env = dict(os.environ, BFQ_NO_OUTMAP="1")                         # the pwrite route
+    p3 = str(tmp_path / "three.bin")
+    open(p3, "wb").close()
+    assert subprocess.run([sys.executable, "-c", code, str(tmp_path / "d.npy"), p3, "0", str(len(data))], env=env, timeout=300).returncode == 0
+    assert np.array_equal(np.fromfile(p3, np.uint8), data)
