@@ -303,7 +303,7 @@ def global_mode(api, parallel, eng, text, N, L, dna_ref, qs_ref, log):
                 f.write(mv[o:o + (1 << 30)])
         names = parallel.output_names([d + "/in.fastq"], d + "/G", False)
         t0 = time.perf_counter()
-        tot = parallel.run_global(eng, parallel.Comm(), [d + "/in.fastq"], names, want_fastq=False, want_streams=True, pinned=True)
+        tot = parallel.run_global(eng, parallel.Comm(), [d + "/in.fastq"], names, want_fastq=False, want_streams=True)
         dt = time.perf_counter() - t0
         same = bool(np.array_equal(np.fromfile(names[0]["dna"], np.uint8), dna_ref) and np.array_equal(np.fromfile(names[0]["qs"], np.uint8), qs_ref))
         log(f"global mode: {dt:.2f}s {tot['seconds']} parity={same}")

@@ -18,7 +18,7 @@ SYMBOLS = [
     "bfq_smooth_invert", "bfq_run_reads", "bfq_run_reads_device", "bfq_fetch_ebwt",
     "bfq_fastq_out_bound", "bfq_fastq_build_ebwt", "bfq_fastq_run", "bfq_fastq_run_streams",
     "bfq_smooth_invert_fastq", "bfq_fastq_run_job", "bfq_host_alloc", "bfq_host_free",
-    "bfq_text_count_lines", "bfq_text_nth_newline", "bfq_file_put", "bfq_fastq_build_ebwt_fd", "bfq_smooth_invert_fastq_fd",
+    "bfq_text_count_lines", "bfq_text_nth_newline", "bfq_file_put", "bfq_file_map", "bfq_file_unmap", "bfq_fastq_build_ebwt_fd", "bfq_smooth_invert_fastq_fd",
     "bfq_glob_begin", "bfq_glob_local_text", "bfq_glob_pile_counts", "bfq_glob_init_out", "bfq_glob_run_pile", "bfq_glob_finish",
     "bfq_synth_default", "bfq_synth_total", "bfq_synth_host", "bfq_synth_device", "bfq_synth_fastq",
     "bfq_prof_enable", "bfq_prof_reset", "bfq_prof_count", "bfq_prof_get", "bfq_prof_trace_select", "bfq_prof_trace",
@@ -140,6 +140,9 @@ def lib():
         L.bfq_host_free.argtypes = [vp]
         L.bfq_text_count_lines.argtypes = [vp, u64, u64, vp, C.c_int]
         L.bfq_file_put.argtypes = [C.c_int, u64, vp, u64, C.c_int]
+        L.bfq_file_map.restype = vp
+        L.bfq_file_map.argtypes = [C.c_int, u64, u64, C.c_int]
+        L.bfq_file_unmap.argtypes = [vp, u64, u64]
         L.bfq_text_nth_newline.restype = C.c_int64
         L.bfq_text_nth_newline.argtypes = [vp, u64, u64]
         L.bfq_synth_default.argtypes = [C.POINTER(Synth), u64, C.c_uint32]

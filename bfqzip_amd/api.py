@@ -93,8 +93,29 @@ def file_put(fd, data, offset, threads=0):
             raise BfqError(rc, "bfq_file_put")
 
 
+class FileRange:
+    """The byte range [offset, offset + nbytes) of an open file as a uint8 array whose pages are the file's (bfq_file_map:
+    allocated, mapped and populated by a few threads): an output buffer that needs no writing afterwards.  .array is None
+    when the file cannot be mapped.  close() unmaps."""
+
+    def __init__(self, fd, offset, nbytes, threads=0):
+        self.L = _lib.lib()
+        self.offset, self.nbytes = int(offset), int(nbytes)
+        self.ptr = self.L.bfq_file_map(fd, self.offset, self.nbytes, threads) if self.nbytes else None
+        self.array = np.ctypeslib.as_array((C.c_uint8 * self.nbytes).from_address(self.ptr)) if self.ptr else None
+
+    def close(self):
+        if getattr(self, "ptr", None):
+            self.array = None
+            self.L.bfq_file_unmap(self.ptr, self.offset, self.nbytes)
+            self.ptr = None
+
+    __del__ = close
+
+
 class HostText:
     """Host-side text helpers of libbfqhip.so (no GPU involved)."""
+    FileRange = FileRange
     text_line_counts = staticmethod(text_line_counts)
     text_nth_newline = staticmethod(text_nth_newline)
     file_put = staticmethod(file_put)
@@ -305,15 +326,15 @@ class Engine:
         sl = int(dna.numel())
         out = out or {}
 
-        def buf(key, want, size):
+        def buf(key, want, need, slack):
             if not want:
                 return None
-            b = out.get(key)
-            return b if (b is not None and len(b) >= size) else np.empty(size, np.uint8)
-        bf = buf("fastq", fastq, text_len + 32)
-        bd = buf("dna", streams, sl + 16)
-        bq = buf("qs", streams, sl + 16)
-        bh = buf("hdr", hdr, text_len + 16)
+            b = out.get(key)                     # a caller's buffer of the exact size will do (e.g. a mapped file range)
+            return b if (b is not None and len(b) >= need) else np.empty(need + slack, np.uint8)
+        bf = buf("fastq", fastq, text_len, 32)
+        bd = buf("dna", streams, sl, 16)
+        bq = buf("qs", streams, sl, 16)
+        bh = buf("hdr", hdr, text_len, 16)
         if bf is not None:
             J.out_fastq = bf.ctypes.data; J.cap_fastq = len(bf)
         if bd is not None:

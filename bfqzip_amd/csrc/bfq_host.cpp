@@ -528,3 +528,45 @@ extern "C" int bfq_file_put(int fd, uint64_t off, const void *src, uint64_t len,
     for (auto &x : th) x.join();
     return munmap(map, (size_t)(off + len - a0)) == 0 ? BFQ_OK : BFQ_E_IO;
 }
+
+// The same for a caller that wants to fill the range itself (the library's transfers then copy straight into the file's
+// pages instead of into a buffer that is written out afterwards): the byte range [off, off + len) of the file, allocated
+// (fallocate), mapped and populated by a few threads; nullptr when the file cannot be mapped.  bfq_file_unmap() with the
+// same off / len gives it back (the pages stay in the page cache: the data is written).
+extern "C" void *bfq_file_map(int fd, uint64_t off, uint64_t len, int threads)
+{
+    if (fd < 0 || !len || bfq_env().noOutmap) return nullptr;
+    const long pg = sysconf(_SC_PAGESIZE);
+    const uint64_t a0 = off / (uint64_t)pg * (uint64_t)pg;
+    if (fallocate(fd, 0, (off_t)off, (off_t)len) != 0) return nullptr;
+    void *m = mmap(nullptr, (size_t)(off + len - a0), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)a0);
+    if (m == MAP_FAILED) return nullptr;
+#ifdef MADV_POPULATE_WRITE
+    int T = threads > 0 ? threads : (bfq_cpu_budget() >= 8 ? 4 : 2);
+    const uint64_t S = 64ull << 20, span = off + len - a0, ns = (span + S - 1) / S;
+    if ((uint64_t)T > ns) T = (int)ns;
+    std::atomic<uint64_t> next{0};
+    auto work = [&] {
+        for (;;) {
+            const uint64_t i = next.fetch_add(1);
+            if (i >= ns) return;
+            const uint64_t b = i * S, e = b + S < span ? b + S : span;
+            (void)madvise((char *)m + b, (size_t)(e - b), MADV_POPULATE_WRITE);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+#else
+    (void)threads;
+#endif
+    return (char *)m + (off - a0);
+}
+extern "C" int bfq_file_unmap(void *p, uint64_t off, uint64_t len)
+{
+    if (!p) return BFQ_E_ARG;
+    const long pg = sysconf(_SC_PAGESIZE);
+    const uint64_t a0 = off / (uint64_t)pg * (uint64_t)pg;
+    return munmap((char *)p - (off - a0), (size_t)(off + len - a0)) == 0 ? BFQ_OK : BFQ_E_IO;
+}

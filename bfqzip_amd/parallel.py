@@ -348,6 +348,30 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
             comm.broadcast_(q8[lo:hi], src)
     lap("text exchange")
     tot = {"blocks": 1, "reads": sum(Np), "bases": sum(Tp), "stats": {}, "seconds": tm}
+    # The stream files' sizes are known from here on (one byte per row): they are created now, and this rank's byte range of
+    # each is mapped and populated by a helper thread while the piles are sorted -- the streams then leave the GPU straight
+    # into the files' pages, with nothing to write afterwards (one input file; with two the shares of both go through a buffer).
+    kinds = [k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w]
+    if comm.rank == 0:
+        for f in range(nf):
+            for k in kinds:
+                open(names[f][k], "wb").close()
+    comm.barrier()
+    direct, direct_thread = {}, None
+    FileRange = getattr(host, "FileRange", None)
+    if want_streams and nf == 1 and FileRange is not None and not out_bufs and not pinned and sum(myrows) >= (1 << 20):
+        import threading
+        off0 = int(sz[:r, 0].sum())
+
+        def _map_streams():
+            for kind in ("dna", "qs"):
+                fd = os.open(names[0][kind], os.O_RDWR)
+                fr = FileRange(fd, off0, myrows[0])
+                os.close(fd)
+                if fr.array is not None:
+                    direct[kind] = fr
+        direct_thread = threading.Thread(target=_map_streams)
+        direct_thread.start()
     sym = torch.empty_like(t8); qual = torch.empty_like(t8)
     if n:
         tsync()
@@ -382,17 +406,19 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
         dna = torch.empty(0, dtype=torch.uint8, device=dev); qs = dna.clone()
     tsync()
     pins = None
+    if direct_thread is not None:
+        direct_thread.join()
+        if len(direct) == 2:
+            out_bufs = {k: fr.array for k, fr in direct.items()}
+        else:
+            for fr in direct.values():
+                fr.close()
+            direct = {}
     if pinned and not out_bufs:
         pins, out_bufs = _pinned_outputs([k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w], int(tlen) + 64)
     res = eng.glob_finish(dna, qs, keep_headers=headers, fastq=want_fastq, streams=want_streams, hdr=want_hdr, text_len=int(tlen), nparts=nf,
                           **({"out": out_bufs} if out_bufs else {}))
     # outputs at their final offsets: output f = the shares of part f of all ranks, in rank order
-    kinds = [k for k, w in zip(KINDS, (want_fastq, want_streams, want_streams, want_hdr)) if w]
-    if comm.rank == 0:
-        for f in range(nf):
-            for k in kinds:
-                open(names[f][k], "wb").close()
-    comm.barrier()
     data = {"fastq": res.fastq, "dna": res.dna, "qs": res.qs, "hdr": res.hdr}
     cut = {"fastq": res.part_fastq_off, "dna": res.part_stream_off, "qs": res.part_stream_off, "hdr": res.part_hdr_off}
     sizes = np.zeros((nf, 4), np.int64)
@@ -405,14 +431,21 @@ def run_global(eng, comm, inputs, names, headers=False, want_fastq=True, want_st
     for f in range(nf):
         for ki, kind in enumerate(KINDS):
             if kind in kinds:
+                if kind in direct:                                   # already in the file's pages
+                    assert int(before[f, ki]) == direct[kind].offset and int(sizes[f, ki]) == direct[kind].nbytes
+                    continue
                 fd = os.open(names[f][kind], os.O_RDWR)
                 if sizes[f, ki]:
                     pwrite_all(fd, data[kind][cut[kind][f]:cut[kind][f + 1]], int(before[f, ki]), host)
                 os.close(fd)
-    if pins:
+    if pins or direct:
         del res, data
+        out_bufs = None
+    if pins:
         for pb in pins.values():
             pb.free()
+    for fr in direct.values():
+        fr.close()
     comm.barrier()
     lap("format+write")
     keys = sorted(tot["stats"]) if tot["stats"] else ["num_clust", "num_clust_discarded", "num_clust_amb_discarded", "num_clust_mod",

@@ -244,6 +244,11 @@ int     bfq_text_count_lines(const uint8_t *h_text, uint64_t len, uint64_t chunk
  * (BFQzip_parallel.py:137-179 merges with `cat`).  fd must be open for reading and writing; the file grows as needed and is
  * never shrunk, so several processes may fill different ranges of one file.  threads 0: by the CPU budget.  Host only. */
 int     bfq_file_put(int fd, uint64_t offset, const void *src, uint64_t len, int threads);
+/* ... or the range itself as memory to fill (allocated, mapped, populated by a few threads): an output buffer for
+ * bfq_fastq_run_job / bfq_glob_finish that IS the file -- no copy afterwards.  NULL when the file cannot be mapped;
+ * bfq_file_unmap() takes the same offset and length. */
+void   *bfq_file_map(int fd, uint64_t offset, uint64_t len, int threads);
+int     bfq_file_unmap(void *p, uint64_t offset, uint64_t len);
 int64_t bfq_text_nth_newline(const uint8_t *h_text, uint64_t len, uint64_t k);
 
 /* Device-resident eBWT of the last bfq_run_reads*() / bfq_build_ebwt() call
