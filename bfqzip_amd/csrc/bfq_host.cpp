@@ -306,7 +306,7 @@ struct PopSlot {
     PopSlot()
     {
         int lim = bfq_env().prefaultThreads;
-        if (lim <= 0) lim = 2;                                   // fallocate + populate of present pages: 2 threads do > 10 GB/s
+        if (lim <= 0) lim = 3;                                   // fallocate + populate of present pages: 2-3 threads do > 10 GB/s
         std::unique_lock<std::mutex> lk(g_popMu);
         g_popCv.wait(lk, [&] { return g_popBusy < lim; });
         g_popBusy++;
@@ -378,7 +378,7 @@ bfq_outmap *bfq_outmap_open(int fd, uint64_t map_len, uint64_t prefault_len)
     const uint64_t pe0 = m->preEnd.load();
     int T = bfq_env().prefaultThreads;
     if (T < 0) {
-        T = bfq_cpu_budget() >= 8 ? 2 : 1;
+        T = bfq_cpu_budget() >= 16 ? 3 : bfq_cpu_budget() >= 8 ? 2 : 1;
     }
     if (pe0 < (64ull << 20)) T = 0;                              // small outputs: not worth a thread
     m->alive = T;

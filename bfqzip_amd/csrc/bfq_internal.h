@@ -33,7 +33,7 @@ extern const char *const BFQ_KERNEL_NAMES[K_NUM];
 
 struct ProfRec { int id; hipEvent_t a, b; double bytes; };
 
-#define BFQ_IO_MAX_WORKERS 8
+#define BFQ_IO_MAX_WORKERS 16
 #define BFQ_IO_STAGE_BYTES (16u << 20)
 
 // device-side counters / small outputs read back by the host (one hipMemcpy)
