@@ -173,7 +173,7 @@ def stream_codec(api, eng, outs, lens, N, L, log, with_cpu, text=None):
         t1 = time.perf_counter()
         back = eng.stream_decompress(blob, out=pback.array)
         dt2 = time.perf_counter() - t1
-        ok = bool(len(back) == len(raw) and np.array_equal(back[:1 << 24], raw[:1 << 24]) and np.array_equal(back[-(1 << 24):], raw[-(1 << 24):]))
+        ok = bool(len(back) == len(raw) and np.array_equal(back, raw))     # the whole stream (the container's checksum was verified by the decoder as well)
         res[k] = {"raw_bytes": int(len(raw)), "compressed_bytes": int(len(blob)), "bits_per_symbol": round(8.0 * len(blob) / max(len(raw), 1), 4),
                   "compress_wall_ms": round(dt * 1e3, 1), "decompress_wall_ms": round(dt2 * 1e3, 1), "round_trip_ok": ok,
                   "kernel_ms": round(pr.get("k_codec", {}).get("ms", 0.0), 1)}

@@ -11,7 +11,9 @@ identical suffixes shuffled, the FASTQ job (text in, FASTQ text + streams out) a
 (parallel.run_global on one rank: two-symbol piles, position-mode clusters) against the same.
 Since the stream codec exists every case also checks step 5 (containers = CPU statement, eBWT-domain containers back to the streams).
 Round 2 totals: 31 992 cases / 8.4 G rows in fifteen runs (the last ten with the 40-bit sort key, the last three with the
-step-5 checks, one of those pile by pile), all bit-exact."""
+step-5 checks, one of those pile by pile), all bit-exact.
+Round 3 adds per case: the capped mode (bfq_params.piles = 2: run_reads and the FASTQ job) and the global mode's streams
+(written through the mapped output files)."""
 import sys, time, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -83,6 +85,16 @@ def run_case(eng, O, seed):
     ob, oq, st = O.run_reads(b, q, r, p)
     hb, hq, hst = eng.run_reads(b, q, r)
     ok = ok and np.array_equal(hb, ob) and np.array_equal(hq, oq) and all(st[k] == hst[k] for k in st)
+    if par["k"] >= 1:                                         # round 3: the capped mode (workspace cap: two-symbol piles, position-mode
+        eng.set_params(piles=2, **par)                        # clusters, no eBWT, no inversion) = the same reads and statistics
+        cb, cq, cst = eng.run_reads(b, q, r)
+        ok = ok and np.array_equal(cb, ob) and np.array_equal(cq, oq) and all(st[k] == cst[k] for k in st)
+        if len(bwt) <= 200000:
+            from bfqzip_amd import fastq as _fq
+            cres = eng.fastq_job([_fq.format_fastq(b, q, r)], fastq=True, streams=True)
+            ok = ok and cres.fastq.tobytes() == _fq.format_fastq(ob, oq, r) and cres.dna.tobytes() == _fq.format_lines(ob, r) \
+                and cres.qs.tobytes() == _fq.format_lines(oq, r)
+        eng.set_params(piles=piles, **par)
     if len(bwt):
         sb, sq, sroff, sst = eng.smooth_invert(bwt, qs)
         ok = ok and np.array_equal(sb, ob) and np.array_equal(sq, oq) and np.array_equal(sroff, r)
@@ -113,8 +125,9 @@ def run_case(eng, O, seed):
             with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as d:
                 open(d + "/in.fastq", "wb").write(text)
                 names = parallel.output_names([d + "/in.fastq"], d + "/G", False)
-                tot = parallel.run_global(eng, parallel.Comm(), [d + "/in.fastq"], names)
+                tot = parallel.run_global(eng, parallel.Comm(), [d + "/in.fastq"], names, want_streams=True)
                 ok = ok and open(names[0]["fastq"], "rb").read() == res.fastq.tobytes() \
+                    and open(names[0]["dna"], "rb").read() == res.dna.tobytes() and open(names[0]["qs"], "rb").read() == res.qs.tobytes() \
                     and all(tot["stats_all_ranks"][k] == st[k] for k in ("num_clust", "qs_smoothed", "modified", "num_clust_mod", "bases_inside"))
     return ok, len(bwt), "seed %d %s piles %d reads %d rows %d" % (seed, par, piles, len(r) - 1, len(bwt))
 

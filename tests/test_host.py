@@ -214,3 +214,22 @@ def test_file_put_places_ranges_of_one_file(tmp_path):
     open(p3, "wb").close()
     assert subprocess.run([sys.executable, "-c", code, str(tmp_path / "d.npy"), p3, "0", str(len(data))], env=env, timeout=300).returncode == 0
     assert np.array_equal(np.fromfile(p3, np.uint8), data)
+
+
+def test_file_range_is_the_files_pages(tmp_path):
+    """bfq_file_map / FileRange: a byte range of an output file as memory (allocated, mapped, populated): what the global
+    mode hands to the GPU transfers as their destination, so that nothing has to be written afterwards."""
+    path = str(tmp_path / "r.bin")
+    open(path, "wb").close()
+    fd = os.open(path, os.O_RDWR)
+    a = api.FileRange(fd, 5000, 3_000_000)                      # unaligned start, beyond the current end of the file
+    b = api.FileRange(fd, 0, 5000)
+    assert a.array is not None and len(a.array) == 3_000_000 and b.array is not None
+    rng = np.random.default_rng(2)
+    da = rng.integers(0, 256, len(a.array), dtype=np.uint8); db = rng.integers(0, 256, 5000, dtype=np.uint8)
+    a.array[:] = da; b.array[:] = db
+    a.close(); b.close()
+    os.close(fd)
+    got = np.fromfile(path, np.uint8)
+    assert len(got) == 3_005_000 and np.array_equal(got[:5000], db) and np.array_equal(got[5000:], da)
+    assert api.FileRange(os.open(path, os.O_RDWR), 0, 0).array is None      # nothing to map
