@@ -376,7 +376,7 @@ static size_t ws_need(u64 n, u64 N, u64 extra)
     const u64 nb = ceil_div(n + 1, bfq_radix_block_elems(n)) + 8;   // small sorts use smaller radix blocks (bfq_radix_block_elems)
     size_t need = 0;
     need += 4 * (n + 256) + 24 * (n / 256 + 2) + 4096;  // bwt, qual, lcp16, symbol counts per group
-    need += 8 * (n / 21 + 8);                           // packed text
+    need += 8 * bfq_t3_alloc(n / 21 + 3);                           // packed text
     need += 6 * 4 * (n + 256);                          // sort records, ping-pong (2 x 12 B/row)
     need += 256 * nb * 12 + (nb + 4096) * 64;           // radix histograms + scan partials
     need += 16 * (N + 64);                              // offsets / lengths
@@ -401,7 +401,7 @@ static size_t ws_need_given(u64 n, u64 N, u64 extra)
 static size_t ws_need_capped(u64 n, u64 N, u64 pile, u64 extra)
 {
     size_t need = 0;
-    need += 4 * (n + 512) + 8 * (n / 21 + 8);
+    need += 4 * (n + 512) + 8 * bfq_t3_alloc(n / 21 + 3);
     need += 2 * 6 * 12 * (n / 32768 + 2) + 16 * (N + 64);
     if (pile) need += 32 * (pile + 256) + 256 * 12 * (ceil_div(pile + 1, bfq_radix_block_elems(pile)) + 8200) + (pile / 32768 + 4096) * 64;
     need += extra + (96u << 20);
@@ -456,7 +456,7 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     if (!n) return;
     size_t m0 = c->mark();
     u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
-    u64 *text3 = c->alloc<u64>(nwords);
+    u64 *text3 = c->alloc<u64>(bfq_t3_alloc(nwords));
     SortRec A, B;
     const bool abSwap = c->env.abSwap && !c->keepRecs;  // placement experiment: B below A
     size_t mKeep = 0, mB = 0;
@@ -667,7 +667,7 @@ static void steps_capped(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const
     if (c->P.K < 1) throw BfqError{BFQ_E_NOMEM, "the capped mode needs -k >= 1 (with -k 0 every row is in one cluster): raise the workspace cap"};
     const size_t m0 = c->mark();
     const u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
-    u64 *text3 = c->alloc<u64>(nwords);
+    u64 *text3 = c->alloc<u64>(bfq_t3_alloc(nwords));
     u8 *T8 = c->alloc<u8>(n + 64), *Q8 = c->alloc<u8>(n + 64);
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
     if (N) KLAUNCH(c, K_MISC, 4.0 * (double)(n - N), k_lines_init, bfq_grid(N, 16), 256, d_bases, d_quals, d_roff, N, c->P.B, dna, qs);
@@ -1147,7 +1147,7 @@ static void fastq_build_ebwt_oneshot(bfq_ctx *c, int fastq_fd, uint64_t len, int
             bfq_step1_device(c, fq.bases, fq.quals, fq.roff, N, fq.total, term_out, nullptr);
         } else {
             const u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
-            const size_t w3 = (8 * nwords + 255) & ~(size_t)255;
+            const size_t w3 = (8 * bfq_t3_alloc(nwords) + 255) & ~(size_t)255;
             bfq_phase("alloc");
             if (hipMalloc((void **)&tws, 2 * npad + w3 + 8 * (N + 2) + 4096) != hipSuccess) { (void)hipGetLastError(); tws = nullptr; throw BfqError{BFQ_E_NOMEM, "device buffer for the text arrays"}; }
             bfq_phase("gpu");

@@ -292,6 +292,7 @@ struct bfq_outmap {
     std::atomic<uint64_t> done{0};
     uint64_t nslices = 0;
     std::atomic<bool> noFallocate{false};
+    std::atomic<bool> failed{false};                             // pages could not be had (ENOSPC ...): writers use pwrite and report it
     double tOpen = 0, tHelpersDone = 0;
     std::atomic<uint8_t> *state = nullptr;                       // per slice: 0 untouched, 1 being populated, 2 populated
 };
@@ -318,15 +319,20 @@ static void populate_slice(bfq_outmap *m, uint64_t idx)
 {
     PopSlot slot;
     const uint64_t b = idx * PF_SLICE, e = std::min<uint64_t>(b + PF_SLICE, m->mapLen);
-    bool ok = false;
-    if (!m->noFallocate && fallocate(m->fd, 0, (off_t)b, (off_t)(e - b)) != 0) m->noFallocate = true;   // not every file system can
-#ifdef MADV_POPULATE_WRITE
-    ok = madvise(m->map + b, (size_t)(e - b), MADV_POPULATE_WRITE) == 0;
-#endif
-    if (!ok) {                                                   // older kernels: touch every page (the file is new: all zero)
-        const long pg = sysconf(_SC_PAGESIZE);
-        for (uint64_t o = b; o < e; o += (uint64_t)pg) ((volatile char *)m->map)[o] = 0;
+    if (m->failed.load()) return;
+    if (!m->noFallocate && fallocate(m->fd, 0, (off_t)b, (off_t)(e - b)) != 0) {
+        // no room (or a quota): touching the mapping would end in SIGBUS -- from here on this file is written with pwrite,
+        // which reports the error.  Anything else: a file system without fallocate, the populate below does the allocation.
+        if (errno == ENOSPC || errno == EDQUOT || errno == EFBIG) { m->failed = true; return; }
+        m->noFallocate = true;
     }
+#ifdef MADV_POPULATE_WRITE
+    if (madvise(m->map + b, (size_t)(e - b), MADV_POPULATE_WRITE) != 0) {
+        if (errno == ENOMEM || errno == EFAULT || errno == ENOSPC) { m->failed = true; return; }   // (EFAULT: the fault would have been a SIGBUS)
+        if (errno != EINVAL) { m->failed = true; return; }
+        // EINVAL: a kernel without MADV_POPULATE_WRITE: the copy takes the faults itself
+    }
+#endif
     m->done += e - b;
 }
 static void prefault_worker(bfq_outmap *m)
@@ -341,9 +347,11 @@ static void prefault_worker(bfq_outmap *m)
     if (--m->alive == 0) m->tHelpersDone = now_s();
 }
 // the bytes [off, off + len) of the mapping are about to be written: returns once their pages are populated
-void bfq_outmap_ensure(bfq_outmap *m, uint64_t off, uint64_t len)
+// false: the pages cannot be had -- write the bytes with pwrite(bfq_outmap_fd(m), ...) instead, it will say why
+bool bfq_outmap_ensure(bfq_outmap *m, uint64_t off, uint64_t len)
 {
-    if (!m || !len) return;
+    if (!m || !len) return true;
+    if (m->failed.load()) return false;
     const uint64_t s0 = off / PF_SLICE, s1 = std::min<uint64_t>((off + len - 1) / PF_SLICE, m->nslices - 1);
     for (uint64_t idx = s0; idx <= s1; idx++) {
         for (;;) {
@@ -354,10 +362,13 @@ void bfq_outmap_ensure(bfq_outmap *m, uint64_t off, uint64_t len)
                 uint8_t z = 0;
                 if (m->state[idx].compare_exchange_strong(z, 1)) { populate_slice(m, idx); m->state[idx].store(2); break; }
             }
+            if (m->failed.load()) return false;
             usleep(200);
         }
     }
+    return !m->failed.load();
 }
+int bfq_outmap_fd(bfq_outmap *m) { return m ? m->fd : -1; }
 
 // Sizes fd to map_len bytes, maps it shared and starts helper threads that fault in [0, prefault_len).  Returns nullptr
 // when the descriptor cannot be mapped (a pipe, /dev/null ...): the caller then writes with pwrite.

@@ -43,4 +43,5 @@ char *bfq_outmap_ptr(bfq_outmap *m);
 uint64_t bfq_outmap_len(bfq_outmap *m);
 void bfq_outmap_extend(bfq_outmap *m, uint64_t prefault_len);
 bool bfq_outmap_close(bfq_outmap *m, uint64_t final_len);
-void bfq_outmap_ensure(bfq_outmap *m, uint64_t off, uint64_t len);   // before copying into [off, off + len)
+bool bfq_outmap_ensure(bfq_outmap *m, uint64_t off, uint64_t len);   // before copying into [off, off + len); false: use pwrite on bfq_outmap_fd()
+int bfq_outmap_fd(bfq_outmap *m);

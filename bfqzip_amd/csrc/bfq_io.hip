@@ -100,7 +100,10 @@ static bool host_get(const HostRef &h, size_t off, char *dst, size_t sz)
 static bool host_put(const HostRef &h, size_t off, const char *src, size_t sz)
 {
     if (h.ptr) {
-        if (h.om) bfq_outmap_ensure(h.om, h.off + off, sz);
+        if (h.om && !bfq_outmap_ensure(h.om, h.off + off, sz)) {    // no pages to be had (disk full ...): pwrite reports it
+            HostRef f = HostRef::file(bfq_outmap_fd(h.om), h.off);
+            return host_put(f, off, src, sz);
+        }
         memcpy((char *)h.ptr + off, src, sz);
         return true;
     }

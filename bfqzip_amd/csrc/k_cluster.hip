@@ -107,7 +107,7 @@ __device__ __forceinline__ u8 prec_sym(const ClusterArgs &a, u64 j)
     const u64 p = row_pos(a, j);                               // bwt[j] = text[p - 1], the one before it text[p - 2]
     if (p < 2) return (u8)a.term;
     const u64 t = p - 2, w = t / BFQ_SYMS_PER_WORD;
-    const u32 code = (u32)(a.text3[w] >> (3u * (20u - (u32)(t - w * BFQ_SYMS_PER_WORD)))) & 7u;
+    const u32 code = (u32)(a.text3[bfq_t3_at(w)] >> (3u * (20u - (u32)(t - w * BFQ_SYMS_PER_WORD)))) & 7u;
     return code ? bfq_code_sym(code) : (u8)a.term;
 }
 

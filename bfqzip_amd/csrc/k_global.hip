@@ -104,7 +104,7 @@ extern "C" int bfq_glob_local_text(bfq_ctx *c, uint8_t *d_T8, uint8_t *d_Q8)
         if (!n) return;
         size_t mk = c->mark();
         u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
-        u64 *text3 = c->alloc<u64>(nwords);                     // by-product of the existing text builder, not used here
+        u64 *text3 = c->alloc<u64>(bfq_t3_alloc(nwords));                     // by-product of the existing text builder, not used here
         u8 *T8 = c->alloc<u8>(n + 64), *Q8 = c->alloc<u8>(n + 64);
         bfq_build_text(c, fq.bases, fq.quals, fq.roff, fq.N, n, T8, Q8, text3, nwords);
         HIP_CHECK(hipMemcpyAsync(d_T8, T8, n, hipMemcpyDeviceToDevice, c->stream));
@@ -158,10 +158,10 @@ extern "C" int bfq_glob_run_pile(bfq_ctx *c, const uint8_t *d_T8, const uint8_t 
         // complexity or amplicon libraries put far more than the usual n / 16 into one pile); else sized generously from n
         const u64 known = (c->globN == n) ? c->globCounts[6 * s + s2] : 0;
         const u64 cap = (known ? known : n / 4) + (1u << 20);
-        c->reserve(8 * (n / 21 + 8) + 40 * (n / BFQ_RS_BLOCK_ELEMS + 64) * 8 + 30 * (cap + 256) + 12 * 256 * (ceil_div(cap + 1, bfq_radix_block_elems(cap)) + 8200) + (cap + 4096) / 32768 * 64 + (128u << 20));
+        c->reserve(8 * bfq_t3_alloc(n / 21 + 3) + 40 * (n / BFQ_RS_BLOCK_ELEMS + 64) * 8 + 30 * (cap + 256) + 12 * 256 * (ceil_div(cap + 1, bfq_radix_block_elems(cap)) + 8200) + (cap + 4096) / 32768 * 64 + (128u << 20));
         c->zeroCounters();
         const u64 nwords = n / BFQ_SYMS_PER_WORD + 3;
-        u64 *text3 = c->alloc<u64>(nwords);
+        u64 *text3 = c->alloc<u64>(bfq_t3_alloc(nwords));
         bfq_pack_text(c, d_T8, n, text3, nwords);
         PileRows pr;
         c->n = 0; c->N = 0;

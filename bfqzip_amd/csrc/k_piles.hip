@@ -99,7 +99,8 @@ __global__ __launch_bounds__(256) void k_build_keys_pile(const u8 *__restrict__ 
             u32 tot;
             const u32 ex = bfq_block_exscan32((u32)__popc(match), scan, &tot);
             if (match) {
-                const u64 t0 = text3[w0], t1 = text3[w0 + 1], t2 = text3[w0 + 2];    // 16 windows span at most 3 words
+                const u64 *t3 = text3 + bfq_t3_at(w0);
+                const u64 t0 = t3[0], t1 = t3[1], t2 = t3[2];                        // 16 windows span at most 3 words
                 const u64 clo = (u64)c[0] | ((u64)c[1] << 32), chi = (u64)c[2] | ((u64)c[3] << 32);
                 const u64 qlo = (u64)q[0] | ((u64)q[1] << 32), qhi = (u64)q[2] | ((u64)q[3] << 32);
                 u64 d = dst + ex;
@@ -163,7 +164,7 @@ size_t bfq_ws_need_piles(u64 n, u64 N, u64 cap, u64 extra, bool lean)
     if (lean) need += 2 * (cap + 256) + 4096;                    // lcp16 of one pile
     else {
         need += 4 * (n + 256) + 4096;                            // bwt, qual, lcp16
-        need += 8 * (n / 21 + 8) + 2 * (n + 256);                // packed text, T8, Q8
+        need += 8 * bfq_t3_alloc(n / 21 + 3) + 2 * (n + 256);                // packed text, T8, Q8
     }
     need += 6 * 4 * (cap + 256);                                 // sort records of one pile, ping-pong
     need += 256 * nbc * 12 + (nbc + 4096) * 64;                  // radix histograms + scan partials
@@ -193,7 +194,7 @@ void bfq_step1_piles(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64
     u8 *T8, *Q8;
     if (pre) { text3 = pre->text3; T8 = pre->T8; Q8 = pre->Q8; }
     else {
-        text3 = c->alloc<u64>(nwords);
+        text3 = c->alloc<u64>(bfq_t3_alloc(nwords));
         T8 = c->alloc<u8>(n + 64); Q8 = c->alloc<u8>(n + 64);
         bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
     }

@@ -56,8 +56,9 @@ __device__ __forceinline__ void wo_key2(const u64 *__restrict__ text3, u64 v, u3
     // two memory requests instead of three: one 16-byte load for the first two words (8-byte alignment is enough for it);
     // same-box A/B at 30 M x 150: k_refine_chunk 146.5 -> 140.0 ms
     typedef unsigned long long u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));   // the address is 8-byte aligned only: say so (ulonglong2 claims 16)
-    const u64x2_a8 t01 = *(const u64x2_a8 *)(text3 + w);
-    const u64 t0 = t01.x, t1 = t01.y, t2 = text3[w + 2];
+    const u64 *t3 = text3 + bfq_t3_at(w);                        // the three words lie in one 64-byte sector
+    const u64x2_a8 t01 = *(const u64x2_a8 *)t3;
+    const u64 t0 = t01.x, t1 = t01.y, t2 = t3[2];
     u64 a = (t0 << o) & BFQ_M63, b = (t1 << o) & BFQ_M63;
     if (o) { a |= t1 >> (63u - o); b |= t2 >> (63u - o); }
     W1 = bfq_mask_key(a);

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n,
                 v = (v << 3) | c;
             }
         }
-        text3[w] = v;
+        text3[bfq_t3_at(w)] = v;
+        const u64 j = w / BFQ_T3_PER_SEC, r = w - j * BFQ_T3_PER_SEC;
+        if (r < 2 && j) text3[(j - 1) * 8 + 6 + r] = v;             // ... and as word 6 / 7 of the sector before
     }
 }
 
@@ -108,7 +110,8 @@ __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, c
             u32 c4 = 0, q4 = 0;                                       // codes / qualities of text positions p0-1 .. p0+2
             if (p0 >= 1 && p0 + 3 <= n) { c4 = *(const u32 *)(T8 + p0 - 1); q4 = *(const u32 *)(Q8 + p0 - 1); }
             else for (int k = 0; k < 4; k++) { u64 t = p0 + k; if (t >= 1 && t - 1 < n) { c4 |= (u32)T8[t - 1] << (8 * k); q4 |= (u32)Q8[t - 1] << (8 * k); } }
-            u64 t0 = text3[w0], t1 = text3[w0 + 1], t2 = text3[w0 + 2];   // 4 windows span at most 3 words
+            const u64 *t3 = text3 + bfq_t3_at(w0);
+            u64 t0 = t3[0], t1 = t3[1], t2 = t3[2];                   // 4 windows span at most 3 words
             u32 rw0[4];
             u64 rw12[4];
             u64 wd = w0;
@@ -152,14 +155,14 @@ void bfq_build_text(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u64 
         KLAUNCH(c, K_TEXT, 4.0 * (double)(n - N), k_text_from_reads, blocks, 256, d_bases, d_quals, d_roff, N, T8, Q8,
                 c->d_cnt);
     }
-    KLAUNCH(c, K_PACK, (double)n + 8.0 * (double)nwords, k_pack3, bfq_grid(nwords, 256), 256, (const u8 *)T8, n, text3,
-            nwords);
+    bfq_pack_text(c, T8, n, text3, nwords);
 }
 
 
 void bfq_pack_text(bfq_ctx *c, const u8 *T8, u64 n, u64 *text3, u64 nwords)
 {
-    KLAUNCH(c, K_PACK, (double)n + 8.0 * (double)nwords, k_pack3, bfq_grid(nwords, 256), 256, T8, n, text3, nwords);
+    const u64 nl = bfq_t3_logical(nwords);                      // text3 holds bfq_t3_alloc(nwords) words
+    KLAUNCH(c, K_PACK, (double)n + 8.0 * (double)nwords, k_pack3, bfq_grid(nl, 256), 256, T8, n, text3, nl);
 }
 
 void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0)

@@ -22,12 +22,23 @@ int main()
         T.push_back(0);
     }
     size_t n = T.size();
-    std::vector<u64> text3(n / BFQ_SYMS_PER_WORD + 3, 0);
-    for (size_t w = 0; w < text3.size(); w++) {
+    // the packed text as the kernels lay it out (k_pack3): sectors of 8 words holding the logical words [6 j, 6 j + 8)
+    const size_t nwords = n / BFQ_SYMS_PER_WORD + 3;
+    std::vector<u64> text3(bfq_t3_alloc(nwords), 0xDEADBEEFDEADBEEFull);      // what is never written must never be read
+    std::vector<u64> plain(bfq_t3_logical(nwords), 0);
+    for (size_t w = 0; w < plain.size(); w++) {
         u64 v = 0;
         for (int j = 0; j < BFQ_SYMS_PER_WORD; j++) { size_t p = w * BFQ_SYMS_PER_WORD + j; v = (v << 3) | (p < n ? T[p] : 0); }
-        text3[w] = v;
+        plain[w] = v;
+        text3[bfq_t3_at(w)] = v;
+        const size_t js = w / BFQ_T3_PER_SEC, r = w - js * BFQ_T3_PER_SEC;
+        if (r < 2 && js) text3[(js - 1) * 8 + 6 + r] = v;
     }
+    for (size_t w = 0; w + 2 < plain.size() && w < nwords; w++)                // any three consecutive words: one sector, in order
+        for (int k = 0; k < 3; k++) {
+            CHECK(text3[bfq_t3_at(w) + k] == plain[w + k]);
+            CHECK((bfq_t3_at(w) + k) / 8 == bfq_t3_at(w) / 8);
+        }
     auto sym = [&](u64 key, int j) { return (int)((key >> (3 * (20 - j))) & 7); };
     for (size_t p = 0; p < n; p++) {
         u64 key = bfq_key_at(text3.data(), p);

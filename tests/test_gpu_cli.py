@@ -174,3 +174,23 @@ def test_tools_spread_over_gpus_by_lease(tools, tmp_path, engine):
     assert r.returncode == 0 and b"(no lease)" in r.stdout
     r = _run([tools["gsufsort"], fq, "--bwt", "--qs", "-o", str(tmp_path / "bad")], env=dict(os.environ, BFQ_DEVICE="7"))
     assert r.returncode == 1
+
+
+def test_tools_report_a_full_disk(tools, tmp_path, engine):
+    """Outputs that cannot be written (here: a file size limit; a full /dev/shm behaves the same) end in exit status 1 and a
+    message -- not in a SIGBUS on the output mapping, and not in a truncated file with status 0 (BFQzip.py:328-336 only
+    looks at the status)."""
+    import resource, signal
+    fq = str(tmp_path / "in.fastq")
+    _synth_file(engine, fq, 300_000, 100, seed=3)
+
+    def limit():
+        signal.signal(signal.SIGXFSZ, signal.SIG_IGN)                # the write then fails with EFBIG instead of killing the tool
+        resource.setrlimit(resource.RLIMIT_FSIZE, (1 << 20, 1 << 20))
+    r = subprocess.run([tools["gsufsort"], fq, "--bwt", "--qs", "-o", str(tmp_path / "L")], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=300, preexec_fn=limit)
+    assert r.returncode == 1 and b"write" in r.stdout.lower(), r.stdout
+    assert _run([tools["gsufsort"], fq, "--bwt", "--qs", "-o", str(tmp_path / "OK")]).returncode == 0
+    r = subprocess.run([tools["bfq_int"], "-e", str(tmp_path / "OK.bwt"), "-q", str(tmp_path / "OK.bwt.qs"), "-o", str(tmp_path / "L.fq"), "-m", "5"],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300, preexec_fn=limit)
+    assert r.returncode == 1, r.stdout
