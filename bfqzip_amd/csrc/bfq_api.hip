@@ -857,7 +857,31 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
         if (n && N == 0) throw BfqError{BFQ_E_NOT_EBWT, "no terminator in the eBWT"};
         u64 total = n - N;
         bfq_phase("alloc");
-        c->reserve(ws_need_given(n, N, extraWs + (haveLcp ? (size_t)lcp_bytes * n : 0)));
+        bool compact = c->env.compact;
+        if (!compact) {
+            try { c->reserve(ws_need_given(n, N, extraWs + (haveLcp ? (size_t)lcp_bytes * n : 0))); }
+            catch (const BfqError &e) { if (e.code != BFQ_E_NOMEM || !c->wsLimit()) throw; compact = true; }
+        }
+        if (compact) {
+            // under a workspace cap: no LF table -- rank blocks, qualities edited in place, a replacement array; the LCP file
+            // streamed through a window, or the LCP deduced with a ring queue and dropped once the flags exist (k_compact.hip):
+            // 5 (bfq_ext) / 8 (bfq_int) bytes per row + the outputs instead of 17
+            c->reserve(bfq_ws_need_compact(c, n, N, extraWs, haveLcp));
+            bfq_phase("read_h2d");
+            bfq_upload(c, in_qs, h_bwtqs, n);
+            u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
+            u64 *d_roff = c->alloc<u64>(N + 1);
+            u32 *lens = c->alloc<u32>(N + 1);
+            c->d_bwt = in_bwt; c->d_qual = in_qs; c->d_lcp = nullptr; c->d_gcnt = nullptr; c->gcntTerm = -1;
+            bfq_phase("gpu");
+            bfq_steps234_compact(c, in_bwt, in_qs, h_lcp, lcp_bytes, n, N, d_roff, lens, ob, oq);
+            if (hostOut) {
+                if (hostOut->h_dna) bfq_download(c, hostOut->h_dna, ob, total);
+                if (hostOut->h_qs) bfq_download(c, hostOut->h_qs, oq, total);
+            }
+            res->ob = ob; res->oq = oq; res->roff = d_roff; res->N = N; res->total = total;
+            return;
+        }
         bfq_phase("read_h2d");
         // the qualities are not needed before the LF table is built: a pageable / file source is staged by a helper thread
         // while this thread goes on (the LCP deduction from the BWT alone takes longer than the upload)

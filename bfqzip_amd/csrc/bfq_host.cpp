@@ -67,6 +67,8 @@ BfqEnv bfq_env_read()
         e.invertNt = geti("BFQ_INVERT_NT", 1);
         e.noOutmap = getenv("BFQ_NO_OUTMAP") != nullptr;
         e.wsContig = geti("BFQ_WS_CONTIG", 0) != 0;
+        e.compact = geti("BFQ_COMPACT", 0) != 0;
+        e.compactWin = getu("BFQ_COMPACT_WIN", 0);
         e.wsVmmMib = geti("BFQ_WS_VMM", 0);
         e.rsPerm = geti("BFQ_RS_PERM", 0) != 0;
         e.abPad = getu("BFQ_AB_PAD", 0);

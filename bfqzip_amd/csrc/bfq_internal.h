@@ -248,11 +248,21 @@ void bfq_pack_text(bfq_ctx *c, const u8 *T8, u64 n, u64 *text3, u64 nwords);
 RankIndex bfq_rank_build(bfq_ctx *c, const u8 *bwt, const u8 *qs, u64 n, int term, const u32 *gcnt = nullptr);
 void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in);
 // LCP array from the eBWT alone (k_bfs.hip): lcp has n + 1 entries
-void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp, u32 *gcntOut = nullptr);   // gcntOut: [6][n/256+1] symbol counts, kept
+void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp, u32 *gcntOut = nullptr,   // gcntOut: [6][n/256+1] symbol counts, kept
+                      const u64 *rankGiven = nullptr, u64 ringEntries = 0);
 // pm != nullptr: position mode -- no LF table (R.lfq may be null): edits go to the output line streams at the text position
 // each row's sort record carries (k_cluster.hip)
 struct ClusterPos { const u64 *w12; const u64 *text3; u8 *outSym, *outQual; int B; };
-void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, const ClusterPos *pm = nullptr);
+// rm != nullptr: rank mode -- no LF table either: LF from the rank blocks, qualities edited in place (qual == the array the
+// statistics are read from), replaced bases into repl[] (k_compact.hip)
+struct ClusterRank { const u64 *rankBlk; u64 F[6]; u8 *qual, *repl; };
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, const ClusterPos *pm = nullptr,
+                  const ClusterRank *rm = nullptr);
+// steps 2-4 on a given eBWT without the LF table (k_compact.hip): rank blocks + qualities in place + replacement array
+#define BFQ_COMPACT_LCP_WIN (64ull << 20)                 // rows of the LCP file in flight
+size_t bfq_ws_need_compact(bfq_ctx *c, u64 n, u64 N, u64 extra, bool haveLcp);
+void bfq_steps234_compact(bfq_ctx *c, const u8 *bwt, u8 *qual, HostRef lcp, int lcp_bytes, u64 n, u64 N, u64 *d_roff, u32 *lens,
+                          u8 *ob, u8 *oq);
 // LF walks: lengths only, then emission at given offsets
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);
 void bfq_fixed_offsets(bfq_ctx *c, u64 N, u64 L, u64 *d_roff);   // d_roff[i] = i * L, i <= N

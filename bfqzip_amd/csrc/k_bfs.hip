@@ -32,6 +32,7 @@
 //   queue entry: lb (38 bits) | (rb - lb) (25 bits) | leaf (1 bit); longer intervals go to a small side list.
 #include "bfq_internal.h"
 #include "bfq_device.h"
+#include "bfq_rankblk.h"
 
 #define BQ_LB_BITS 38
 #define BQ_LB_MASK ((1ull << BQ_LB_BITS) - 1ull)
@@ -45,7 +46,8 @@ struct BfsArgs {
     const u64 *rank;        // [n/64 + 2][8]
     u64 F[6];               // first row of every symbol's suffixes (# A C G N T)
     u16 *lcp;               // [n + 1]
-    u64 *queue;             // [n + 64]
+    u64 *queue;             // [n + 64]; ring mode (qmask != 0): [qmask + 1], positions taken modulo its size
+    u64 qmask;
     u64 *tail;              // [0] next free queue slot, [1] / [2] lengths of the two side lists, [3] LCP entries written, [4] fill list length
     u64 *side[2];           // long intervals (lb, rb | leaf) of the current / next level
     u64 sideCap;
@@ -87,29 +89,6 @@ __global__ __launch_bounds__(256) void k_rankblocks(const u8 *__restrict__ bwt, 
     if (bad) atomicAdd(&cnt->errSymbol, 1ull);
 }
 
-// one rank block in registers; random blocks are read past the L1 (nontemporal: a block is used once per level)
-struct RankBlk { u64 w[8]; };
-__device__ __forceinline__ RankBlk load_blk(const u64 *__restrict__ rank, u64 blk)
-{
-    RankBlk b;
-    const u64 *p = rank + (blk << 3);
-#pragma unroll
-    for (int k = 0; k < 8; k++) b.w[k] = __builtin_nontemporal_load(p + k);
-    return b;
-}
-// occurrences of the codes 1..5 in rows [0, p), p inside (or at the end of) block b
-__device__ __forceinline__ void occ5(const RankBlk &b, u64 p, u64 *o)
-{
-    const u32 k = (u32)p & 63u;
-    const u64 lo = k ? (~0ull >> (64u - k)) : 0ull;
-    const u64 p0 = b.w[5] & lo, p1 = b.w[6] & lo, p2 = b.w[7] & lo, n0 = ~b.w[5] & lo, n1 = ~b.w[6] & lo, n2 = ~b.w[7] & lo;
-    o[0] = b.w[0] + (u64)__popcll(p0 & n1 & n2);      // A 001
-    o[1] = b.w[1] + (u64)__popcll(n0 & p1 & n2);      // C 010
-    o[2] = b.w[2] + (u64)__popcll(p0 & p1 & n2);      // G 011
-    o[3] = b.w[3] + (u64)__popcll(n0 & n1 & p2);      // N 100
-    o[4] = b.w[4] + (u64)__popcll(p0 & n1 & p2);      // T 101
-}
-
 // Extends the intervals of one level.  SIDE: the (few) long intervals of the side list instead of the queue segment.
 #define BQ_STAGE 4096                                        // children staged in LDS per queue reservation
 template <bool SIDE>
@@ -134,7 +113,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
         bool leaf = false;
         if (valid) {
             if (SIDE) { lb = a.side[cur][2 * i]; rb = a.side[cur][2 * i + 1]; leaf = (rb & BQ_LEAF) != 0; rb &= ~BQ_LEAF; }
-            else { const u64 e = __builtin_nontemporal_load(a.queue + qbeg + i); lb = e & BQ_LB_MASK; rb = lb + ((e >> BQ_LB_BITS) & BQ_LEN_MAX); leaf = (e & BQ_LEAF) != 0; }
+            else { const u64 e = __builtin_nontemporal_load(a.queue + (a.qmask ? ((qbeg + i) & a.qmask) : qbeg + i)); lb = e & BQ_LB_MASK; rb = lb + ((e >> BQ_LB_BITS) & BQ_LEN_MAX); leaf = (e & BQ_LEAF) != 0; }
         }
         u32 nkids = 0;
         u64 kid[5];                                                // packed children to enqueue
@@ -197,7 +176,11 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
             __syncthreads();
             // (a byte sequence that is no eBWT can enqueue more than the n intervals a real one has: the stores stop at the
             // queue's end, the host sees the tail beyond it and reports BFQ_E_NOT_EBWT)
-            for (u32 j = threadIdx.x; j < used; j += 256) if (sBase + j < a.n + 64) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+            for (u32 j = threadIdx.x; j < used; j += 256) {
+                // ring: never onto an entry of the level being read (they start at qbeg); what does not fit is dropped and flagged
+                if (a.qmask) { if (sBase + j - qbeg <= a.qmask) __builtin_nontemporal_store(stage[j], a.queue + ((sBase + j) & a.qmask)); else a.tail[5] = 1; }
+                else if (sBase + j < a.n + 64) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+            }
             __syncthreads();
             used = 0;
         }
@@ -208,7 +191,10 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
     if (used) {
         if (threadIdx.x == 0) sBase = atomicAdd((unsigned long long *)&a.tail[0], (unsigned long long)used);
         __syncthreads();
-        for (u32 j = threadIdx.x; j < used; j += 256) if (sBase + j < a.n + 64) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+        for (u32 j = threadIdx.x; j < used; j += 256) {
+            if (a.qmask) { if (sBase + j - qbeg <= a.qmask) __builtin_nontemporal_store(stage[j], a.queue + ((sBase + j) & a.qmask)); else a.tail[5] = 1; }
+            else if (sBase + j < a.n + 64) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+        }
     }
     const u64 wsum = bfq_readlane64(bfq_wave_incscan64(written), 63);
     if (lane == 0 && wsum) atomicAdd((unsigned long long *)&a.tail[3], (unsigned long long)wsum);
@@ -245,31 +231,45 @@ __global__ __launch_bounds__(256) void k_bfs_init(BfsArgs a, u64 N)
             }
         }
         a.lcp[a.n] = 0;
-        a.tail[0] = q; a.tail[1] = 0; a.tail[2] = ns; a.tail[3] = wr; a.tail[4] = 0;   // level 1 reads side list 1
+        a.tail[0] = q; a.tail[1] = 0; a.tail[2] = ns; a.tail[3] = wr; a.tail[4] = 0; a.tail[5] = 0;   // level 1 reads side list 1
     }
 }
 
 u64 *bfq_symbol_scans(bfq_ctx *c, const u8 *bwt, u64 n, int term, const u32 *gcntIn, u32 *gcntOut);   // k_rank.hip
 
+// rank blocks of an eBWT (rank: (n / 256 + 1) * 4 + 2 blocks of 8 words); the symbol totals land in d_cnt->tot
+void bfq_rank_blocks(bfq_ctx *c, const u8 *bwt, u64 n, int term, const u64 *scanned, u64 *rank)
+{
+    const u64 ngroups = n / 256 + 1;
+    KLAUNCH(c, K_RANK_BUILD, 2.0 * (double)n, k_rankblocks, bfq_grid(ngroups, 4), 256, bwt, n, (u32)(term & 0xFF), scanned, ngroups, rank, c->d_cnt);
+}
+
 // lcp[0..n): LCP array of the eBWT `bwt` (device, n rows, N of them terminators).  Workspace: n bytes of rank blocks,
-// 8 n bytes of queue (released on return).
-void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp, u32 *gcntOut)
+// 8 n bytes of queue (released on return).  rankGiven: the rank blocks exist already (and the symbol totals are in
+// c->h_cnt); ringEntries != 0: the queue is a ring of that many entries (a power of two) instead of a log of n -- only the
+// current level and the one being written are live; a level too wide for it is an error (k_compact.hip, under a cap).
+void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp, u32 *gcntOut, const u64 *rankGiven, u64 ringEntries)
 {
     if (!n) return;
     size_t mk = c->mark();
     const u64 ngroups = n / 256 + 1;
     BfsArgs a;
-    u64 *scanned = bfq_symbol_scans(c, bwt, n, term, nullptr, gcntOut);   // the counts stay for the LF table build
-    u64 *rank = c->alloc<u64>((ngroups * 4 + 2) * 8);
-    KLAUNCH(c, K_RANK_BUILD, 2.0 * (double)n, k_rankblocks, bfq_grid(ngroups, 4), 256, bwt, n, (u32)(term & 0xFF), (const u64 *)scanned, ngroups, rank, c->d_cnt);
-    c->fetchCounters();                                            // symbol totals -> F
+    const u64 *rank = rankGiven;
+    if (!rankGiven) {
+        u64 *scanned = bfq_symbol_scans(c, bwt, n, term, nullptr, gcntOut);   // the counts stay for the LF table build
+        u64 *rk = c->alloc<u64>((ngroups * 4 + 2) * 8);
+        KLAUNCH(c, K_RANK_BUILD, 2.0 * (double)n, k_rankblocks, bfq_grid(ngroups, 4), 256, bwt, n, (u32)(term & 0xFF), (const u64 *)scanned, ngroups, rk, c->d_cnt);
+        c->fetchCounters();                                        // symbol totals -> F
+        rank = rk;
+    }
     {
         u64 acc = 0;
         for (int s = 0; s < 6; s++) { a.F[s] = acc; acc += c->h_cnt.tot[s]; }
         if (acc != n || c->h_cnt.tot[0] != N) throw BfqError{BFQ_E_NOT_EBWT, "symbol counts do not add up to the eBWT"};
     }
     a.rank = rank; a.lcp = lcp; a.n = n;
-    a.queue = c->alloc<u64>(n + 64);
+    a.qmask = ringEntries ? ringEntries - 1 : 0;
+    a.queue = c->alloc<u64>(ringEntries ? ringEntries : n + 64);
     a.tail = c->alloc<u64>(8);
     a.sideCap = (n >> BQ_LEN_BITS) + 16;
     a.side[0] = c->alloc<u64>(2 * a.sideCap); a.side[1] = c->alloc<u64>(2 * a.sideCap);
@@ -277,8 +277,8 @@ void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lc
     a.fill = c->alloc<u64>(2 * a.fillCap);
     HIP_CHECK(hipMemsetAsync(lcp, 0xFF, 2 * (n + 1), c->stream));
     KLAUNCH(c, K_BFS, 2.0 * (double)N, k_bfs_init, bfq_grid(N + 1, 256), 256, a, N);
-    u64 t[5] = {0, 0, 0, 0, 0};
-    HIP_CHECK(hipMemcpyAsync(t, a.tail, 40, hipMemcpyDeviceToHost, c->stream));
+    u64 t[6] = {0, 0, 0, 0, 0, 0};
+    HIP_CHECK(hipMemcpyAsync(t, a.tail, 48, hipMemcpyDeviceToHost, c->stream));
     c->sync();
     u64 qbeg = 0, qend = t[0], nside = t[2];
     int cur = 1;
@@ -288,11 +288,13 @@ void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lc
         // per interval: two 64-B rank blocks, per child one LCP probe + store, 8 B of queue in and out
         if (qend > qbeg)
             KLAUNCH(c, K_BFS, 160.0 * (double)(qend - qbeg), k_bfs_level<false>, bfq_grid(qend - qbeg, 256 * 8), 256, a, qbeg, qend, level, cur);
-        if (nside) KLAUNCH(c, K_BFS, 0.0, k_bfs_level<true>, bfq_grid(nside, 256), 256, a, 0ull, 0ull, level, cur);
-        HIP_CHECK(hipMemcpyAsync(t, a.tail, 40, hipMemcpyDeviceToHost, c->stream));
+        if (nside) KLAUNCH(c, K_BFS, 0.0, k_bfs_level<true>, bfq_grid(nside, 256), 256, a, qbeg, qend, level, cur);
+        HIP_CHECK(hipMemcpyAsync(t, a.tail, 48, hipMemcpyDeviceToHost, c->stream));
         c->sync();
         if (t[0] > n + 32 || t[1 + (cur ^ 1)] > a.sideCap || t[4] > a.fillCap)
             throw BfqError{BFQ_E_NOT_EBWT, "interval refinement overran the eBWT: not a BWT"};
+        if (ringEntries && t[5])                                   // this level + the next one did not fit the ring: children were dropped
+            throw BfqError{BFQ_E_NOMEM, "interval refinement: a level wider than the queue the workspace cap leaves room for; raise bfq_params.ws_cap_mib / BFQ_WS_CAP"};
         if (t[4]) {
             KLAUNCH(c, K_BFS, 0.0, k_bfs_fill, (unsigned)(t[4] < 4096 ? t[4] : 4096), 256, a, t[4], level);
             HIP_CHECK(hipMemsetAsync(a.tail + 4, 0, 8, c->stream));

@@ -21,6 +21,7 @@
 #include "bfq_internal.h"
 #include "bfq_device.h"
 #include "bfq_rank.h"
+#include "bfq_rankblk.h"
 
 // 8 rows per thread: ten LCP values in (two unaligned 8-byte loads + the two neighbours), eight flags out
 __global__ __launch_bounds__(256) void k_lcp_flags(const u16 *__restrict__ lcp, u64 n, int K, u8 *__restrict__ in)
@@ -70,6 +71,13 @@ struct ClusterArgs {
     const u64 *text3;       // packed text (bfq_common.h)
     u8 *outSym, *outQual;   // OUT.fq.dna / OUT.fq.qs layout = terminated text coordinates (read i at roff[i] + i, then '\n')
     int B;
+    // rank mode (rankBlk != nullptr; neither an LF table nor sort records): a given eBWT under a workspace cap
+    // (k_compact.hip).  LF(row) is answered on demand from the 64-byte rank blocks, smoothed qualities replace qual[] in
+    // place and replaced bases go to repl[] (0 = untouched) -- the reference's own arrangement: QUAL[] edited in place,
+    // rankbv bit + BWT_MOD (bfq_int.cpp:386-391).
+    const u64 *rankBlk;
+    u64 F[6];
+    u8 *editQual, *repl;
     u64 *bigStart;          // first in() rows of the clusters left to the k_big_* kernels
     struct BigState *big;   // their state
     u16 *firstOut;          // per CL_WROWS rows: first row with in() == 0 (CL_WROWS: none), for k_big_extent
@@ -93,16 +101,24 @@ __device__ __forceinline__ u64 row_pos(const ClusterArgs &a, u64 j)      // text
 __device__ __forceinline__ void set_qual(const ClusterArgs &a, u64 j, int newqs)
 {
     if (a.w12) { const u32 q = (u32)newqs & 0xFFu; a.outQual[row_pos(a, j) - 1] = (u8)(a.B ? bfq_bin8(q) : q); }
+    else if (a.rankBlk) a.editQual[j] = (u8)newqs;
     else lfq_set_qual(a.R.lfq, j, (u32)newqs & 0xFFu);
 }
 __device__ __forceinline__ void set_mod(const ClusterArgs &a, u64 j, u8 sym)
 {
     if (a.w12) a.outSym[row_pos(a, j) - 1] = sym;
+    else if (a.rankBlk) a.repl[j] = sym;
     else lfq_set_repl(a.R.lfq, j, bfq_base_code(a.bwt[j]), bfq_base_code(sym));
 }
 // the symbol that precedes the eBWT symbol of row j: bwt[LF(j)] (bfq_int.cpp:545-560,577); row j holds a base
 __device__ __forceinline__ u8 prec_sym(const ClusterArgs &a, u64 j)
 {
+    if (a.rankBlk) {                                           // LF(j) = F[c] + rank_c(j) from one rank block (dna_bwt_n.hpp:80-101)
+        const RankBlk b = load_blk(a.rankBlk, j >> 6);
+        const u32 code = blk_code(b, j);
+        if (!code) return (u8)a.term;
+        return a.bwt[a.F[code] + blk_occ_of(b, j, code)];
+    }
     if (!a.w12) return a.bwt[lfq_next(a.R.lfq[j])];
     const u64 p = row_pos(a, j);                               // bwt[j] = text[p - 1], the one before it text[p - 2]
     if (p < 2) return (u8)a.term;
@@ -538,11 +554,14 @@ void bfq_lcp_flags(bfq_ctx *c, const u16 *lcp, u64 n, int K, u8 *in)
     KLAUNCH(c, K_LCP_FLAGS, 3.0 * (double)n, k_lcp_flags, bfq_grid((n + 7) / 8, 256), 256, lcp, n, K, in);
 }
 
-void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, const ClusterPos *pm)
+void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, const ClusterPos *pm,
+                  const ClusterRank *rm)
 {
     if (!n) return;
     ClusterArgs a;
     a.R = R; a.bwt = bwt; a.qual = qual; a.in = in; a.n = n;
+    a.rankBlk = rm ? rm->rankBlk : nullptr; a.editQual = rm ? rm->qual : nullptr; a.repl = rm ? rm->repl : nullptr;
+    for (int s = 0; s < 6; s++) a.F[s] = rm ? rm->F[s] : 0;
     a.w12 = pm ? pm->w12 : nullptr; a.text3 = pm ? pm->text3 : nullptr;
     a.outSym = pm ? pm->outSym : nullptr; a.outQual = pm ? pm->outQual : nullptr; a.B = pm ? pm->B : 0;
     a.m = c->P.m; a.v = c->P.v; a.f = c->P.f; a.t = c->P.t; a.term = c->P.term & 0xFF; a.M = c->P.M; a.ext = c->P.ext;

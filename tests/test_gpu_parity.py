@@ -259,6 +259,79 @@ def test_capped_mode(engine, orc):
     engine.set_params()
 
 
+def test_compact_steps_on_a_given_ebwt(engine, orc, monkeypatch):
+    """bfq_ext's job (eBWT + QS + LCP given) without the LF table (k_compact.hip: rank blocks answered on demand, qualities
+    smoothed in place, replacement array, the LCP streamed through a window): what runs when the workspace cap rules the
+    17 bytes per row of the table out.  Same reads, offsets and statistics as the oracle for every smoothing mode (incl. the
+    bfq_ext arithmetic), 1- / 2- / 4-byte LCP entries, variable-length / empty / N reads, low-complexity reads (clusters of
+    10^5 rows through the tiled kernels), a window of 1000 rows (the LCP in many pieces), and through the FASTQ-writing entry
+    point with a header file; bfq_int's job too (no LCP: deduced on the same rank blocks with a ring queue, dropped once the
+    flags exist).  Then a 2 M-read eBWT under caps that leave no room for the table, in both modes."""
+    monkeypatch.setenv("BFQ_COMPACT", "1")
+
+    def cases():
+        for M in range(4):
+            for ext in (0, 1):
+                sp = api.synth_spec(3000, 50, seed=500 + 2 * M + ext, coverage=25)
+                yield api.synth_host(sp) + (dict(M=M, B=(M + ext) & 1, m=5, ext=ext),)
+        yield api.synth_host(api.synth_spec(4000, 20, Lmax=70, seed=5, coverage=40, err_ppm=20000, n_ppm=15000, snp_every=97, dsnp_every=131)) + (dict(m=5),)
+        rng = np.random.default_rng(79)
+        for it in range(12):
+            b, q, r = util.random_reads(rng, int(rng.integers(1, 300)), 0 if it % 4 == 0 else 1, int(rng.integers(1, 60)))
+            yield b, q, r, dict(M=int(rng.integers(0, 4)), B=int(rng.integers(0, 2)), k=int(rng.choice([0, 1, 2, 3, 5, 16])), m=int(rng.choice([2, 3, 5])))
+        yield _low_complexity(np.random.default_rng(7)) + (dict(m=5, M=1, B=1),)
+    two = 0
+    for ci, (b, q, r, par) in enumerate(cases()):
+        full = dict(k=16, m=2, v=ord(">"), f=40, t=20, M=2, B=0, ext=0); full.update(par)
+        p = orc.params(K=full["k"], m=full["m"], v=full["v"], f=full["f"], t=full["t"], M=full["M"], B=full["B"], ext=full["ext"])
+        bwt, qs, lcp = orc.build_ebwt(b, q, r)
+        if not len(bwt):
+            continue
+        eb, eq, eroff, est = orc.smooth_invert(bwt, qs, lcp.astype(np.uint32), p)
+        if ci % 3 == 1:
+            monkeypatch.setenv("BFQ_COMPACT_WIN", "1000")
+        else:
+            monkeypatch.delenv("BFQ_COMPACT_WIN", raising=False)
+        engine.set_params(**full)
+        for dt in (np.uint8, np.uint16, np.uint32)[ci % 3:][:2]:
+            if dt == np.uint8 and int(lcp.max(initial=0)) > 255:
+                continue
+            gb, gq, groff, gst = engine.smooth_invert(bwt, qs, lcp.astype(dt))
+            assert np.array_equal(gb, eb) and np.array_equal(gq, eq) and np.array_equal(groff, eroff), (ci, par, dt)
+            for k in est:
+                assert est[k] == gst[k], (k, ci, par)
+        ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)            # bfq_int mode
+        assert np.array_equal(ib, eb) and np.array_equal(iq, eq) and np.array_equal(iroff, eroff), (ci, par)
+        for k in est:
+            assert est[k] == ist[k], (k, ci, par)
+        two += est["num_clust_mod"]
+        hdrs = b"".join(b"@h%d\n" % i for i in range(len(r) - 1))
+        txt, _ = engine.smooth_invert_fastq(bwt, qs, lcp=lcp.astype(np.uint32), headers=np.frombuffer(hdrs, np.uint8))
+        from bfqzip_amd import fastq as fq
+        assert txt == fq.format_fastq(eb, eq, eroff, [b"@h%d" % i for i in range(len(r) - 1)])
+    assert two > 0
+    monkeypatch.delenv("BFQ_COMPACT"); monkeypatch.delenv("BFQ_COMPACT_WIN", raising=False)
+    # the cap selects it: 2 M x 100 (n = 202 M rows: the table path needs 3.7 GB, the compact one 1.6 GB)
+    sp = api.synth_spec(2_000_000, 100, seed=12)
+    b, q, r = api.synth_host(sp)
+    engine.set_params(m=5, M=1, B=1)
+    bwt, qs, lcp = engine.build_ebwt(b, q, r)
+    fb, fq_, froff, fst = engine.smooth_invert(bwt, qs, lcp)
+    engine.set_params(m=5, M=1, B=1, ws_cap_mib=2000)
+    cb, cq, croff, cst = engine.smooth_invert(bwt, qs, lcp)
+    assert engine.workspace_bytes() <= 2000 << 20
+    assert np.array_equal(cb, fb) and np.array_equal(cq, fq_) and np.array_equal(croff, froff) and cst == fst
+    engine.set_params(m=5, M=1, B=1, ws_cap_mib=2600)                 # bfq_int mode: + the 16-bit LCP and the ring while the flags are made
+    ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)
+    assert engine.workspace_bytes() <= 2600 << 20
+    assert np.array_equal(ib, fb) and np.array_equal(iq, fq_) and np.array_equal(iroff, froff) and ist == fst
+    engine.set_params(m=5, ws_cap_mib=400)
+    with pytest.raises(api.BfqError) as e:
+        engine.smooth_invert(bwt, qs, lcp)
+    assert "cap" in str(e.value)
+    engine.set_params()
+
+
 def test_position_mode(engine, orc, monkeypatch):
     """The device-resident fused path without LF table and walks (BFQ_POSMODE=1: k_cluster writes its edits to the text
     position every row's sort record carries): same reads and statistics as the oracle -- all smoothing modes with and without
@@ -367,6 +440,7 @@ def test_full_size_properties(engine):
       4. M=1 (configs[4]'s smoothing): same base edits and same smoothed positions as 2. (the decision tree does not
          depend on M), qualities differ only there;
       5. bfq_int mode (LCP deduced from the eBWT alone) on the 4.53 G-row eBWT of run 2: same reads as run 2;
+      5b. steps 2-4 on that eBWT under a 40 GiB cap (no LF table: k_compact.hip), with the LCP given and deduced: the same;
       2b. step 1 pile by pile: same reads and statistics as run 2;
       2c. the capped mode under a 40 GiB workspace cap: same reads and statistics as run 2."""
     torch = pytest.importorskip("torch")
@@ -402,9 +476,21 @@ def test_full_size_properties(engine):
     assert st2 == st                                                        # 2. deterministic
     # 5. bfq_int mode on this run's eBWT (host arrays: the boundary of bfq_smooth_invert)
     n = tot + N
-    bwt, qs, _ = engine.fetch_ebwt(n)
+    bwt, qs, lcp = engine.fetch_ebwt(n)
     ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)
-    del bwt, qs
+    # 5b. the same two jobs under a 40 GiB workspace cap: no LF table (k_compact.hip) -- bfq_ext's (LCP given, streamed
+    #     through a window) and bfq_int's (LCP deduced with a ring queue)
+    import time as _t
+    for label, l in (("bfq_ext", lcp), ("bfq_int", None)):
+        engine.set_params(k=16, m=5, M=2, B=0, v=ord(">"), ws_cap_mib=40 * 1024)
+        t0 = _t.perf_counter(); cb, cq, croff, cst = engine.smooth_invert(bwt, qs, l); dtc = _t.perf_counter() - t0
+        print(f"compact steps 2-4 ({label} job), 30 M x 150 under 40 GiB: workspace {engine.workspace_bytes() / 2**30:.1f} GiB, {dtc * 1e3:.0f} ms host arrays to host arrays")
+        assert engine.workspace_bytes() <= 40 * 2**30
+        assert {k: cst[k] for k in ("num_clust", "qs_smoothed", "modified")} == {k: st[k] for k in ("num_clust", "qs_smoothed", "modified")}
+        assert np.array_equal(cb, ib) and np.array_equal(cq, iq) and np.array_equal(croff, iroff)
+        del cb, cq, croff
+    engine.set_params(k=16, m=5, M=2, B=0, v=ord(">"))
+    del bwt, qs, lcp
     assert {k: ist[k] for k in ("num_clust", "qs_smoothed", "modified")} == {k: st[k] for k in ("num_clust", "qs_smoothed", "modified")}
     assert torch.equal(torch.from_numpy(ib).to(dev), ob) and torch.equal(torch.from_numpy(iq).to(dev), oq)
     assert int(iroff[-1]) == tot and bool((np.diff(iroff.astype(np.int64)) == L).all())
