@@ -563,6 +563,11 @@ def main():
                 "alg_bytes_per_launch": d["alg_bytes"] / d["launches"],
                 "job_alg_bytes_per_base": round(alg_bytes_per_base(L), 1),
                 "job_frac": round(alg_bytes_per_base(L) * (bases_all / world / (dt / args.steps)) / (HBM_PEAK_GBS * 1e9), 4)}
+        # kernels within 10 % of the dominant one's accumulated time (the five scatter passes and the one refinement launch
+        # trade places from run to run): named, so that a change of `roofline.kernel` between two lines is not read as a change of code
+        roof["co_dominant"] = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] / args.steps,
+                                   "frac": round(v["alg_bytes"] / v["launches"] / (v["ms"] / v["launches"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                               for k, v in prof.items() if v["ms"] >= 0.9 * d["ms"] and v["alg_bytes"] > 0}
         kern = {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
         # the same figure for the other heavy kernels (algorithmic GB/s and fraction of the HBM peak)
         # the sort passes one by one (launch order: KEY_PASSES scatters per step; pass 0 reads the records k_build_keys wrote)

@@ -866,15 +866,23 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
             // under a workspace cap: no LF table -- rank blocks, qualities edited in place, a replacement array; the LCP file
             // streamed through a window, or the LCP deduced with a ring queue and dropped once the flags exist (k_compact.hip):
             // 5 (bfq_ext) / 8 (bfq_int) bytes per row + the outputs instead of 17
-            c->reserve(bfq_ws_need_compact(c, n, N, extraWs, haveLcp));
+            // the cap counts the eBWT and the qualities too (the text buffer, outside the arena)
+            const size_t need = bfq_ws_need_compact(c, n, N, extraWs, haveLcp, c->textCap);
+            if (c->wsLimit() && need + c->textCap > c->wsLimit()) {
+                char b[200];
+                snprintf(b, sizeof b, "device memory of %.1f GiB (eBWT + qualities + workspace) is above the cap of %.1f GiB (bfq_params.ws_cap_mib / BFQ_WS_CAP)",
+                         (need + c->textCap) / 1073741824.0, c->wsLimit() / 1073741824.0);
+                throw BfqError{BFQ_E_NOMEM, b};
+            }
+            c->reserve(need);
             bfq_phase("read_h2d");
             bfq_upload(c, in_qs, h_bwtqs, n);
-            u8 *ob = c->alloc<u8>(total + 64), *oq = c->alloc<u8>(total + 64);
+            u8 *ob = nullptr, *oq = nullptr;
             u64 *d_roff = c->alloc<u64>(N + 1);
             u32 *lens = c->alloc<u32>(N + 1);
             c->d_bwt = in_bwt; c->d_qual = in_qs; c->d_lcp = nullptr; c->d_gcnt = nullptr; c->gcntTerm = -1;
             bfq_phase("gpu");
-            bfq_steps234_compact(c, in_bwt, in_qs, h_lcp, lcp_bytes, n, N, d_roff, lens, ob, oq);
+            bfq_steps234_compact(c, in_bwt, in_qs, h_lcp, lcp_bytes, n, N, d_roff, lens, &ob, &oq, extraWs, c->textCap);
             if (hostOut) {
                 if (hostOut->h_dna) bfq_download(c, hostOut->h_dna, ob, total);
                 if (hostOut->h_qs) bfq_download(c, hostOut->h_qs, oq, total);

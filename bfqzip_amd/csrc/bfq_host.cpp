@@ -68,7 +68,9 @@ BfqEnv bfq_env_read()
         e.noOutmap = getenv("BFQ_NO_OUTMAP") != nullptr;
         e.wsContig = geti("BFQ_WS_CONTIG", 0) != 0;
         e.compact = geti("BFQ_COMPACT", 0) != 0;
+        e.prefaultPause = geti("BFQ_PREFAULT_PAUSE", 0) != 0;
         e.compactWin = getu("BFQ_COMPACT_WIN", 0);
+        e.compactRing = getu("BFQ_COMPACT_RING", 0);
         e.wsVmmMib = geti("BFQ_WS_VMM", 0);
         e.rsPerm = geti("BFQ_RS_PERM", 0) != 0;
         e.abPad = getu("BFQ_AB_PAD", 0);
@@ -294,6 +296,9 @@ struct bfq_outmap {
     std::atomic<uint64_t> done{0};
     uint64_t nslices = 0;
     std::atomic<bool> noFallocate{false};
+    std::atomic<uint64_t> fallocDone{0};                         // bytes from the start of the file whose pages exist
+    std::atomic<bool> fallocRunning{false};
+    std::thread fallocThread;
     std::atomic<bool> failed{false};                             // pages could not be had (ENOSPC ...): writers use pwrite and report it
     double tOpen = 0, tHelpersDone = 0;
     std::atomic<uint8_t> *state = nullptr;                       // per slice: 0 untouched, 1 being populated, 2 populated
@@ -309,7 +314,7 @@ struct PopSlot {
     PopSlot()
     {
         int lim = bfq_env().prefaultThreads;
-        if (lim <= 0) lim = 3;                                   // fallocate + populate of present pages: 2-3 threads do > 10 GB/s
+        if (lim <= 0) lim = 2;                                   // populate of present pages: 2 threads map 24 GB/s
         std::unique_lock<std::mutex> lk(g_popMu);
         g_popCv.wait(lk, [&] { return g_popBusy < lim; });
         g_popBusy++;
@@ -317,17 +322,27 @@ struct PopSlot {
     ~PopSlot() { std::lock_guard<std::mutex> g(g_popMu); g_popBusy--; g_popCv.notify_one(); }
 };
 }   // namespace
+// staged uploads in progress (bfq_io.hip): the helpers stand back while a file is being read into the staging buffers --
+// reading 9.5 GB of page cache and allocating 9 GB of it at the same time is slower than one after the other (both work the
+// same LRU lists; BFQ_PREFAULT_PAUSE=0 lets them overlap)
+std::atomic<int> g_bfqUploadsRunning{0};
 static void populate_slice(bfq_outmap *m, uint64_t idx)
 {
-    PopSlot slot;
     const uint64_t b = idx * PF_SLICE, e = std::min<uint64_t>(b + PF_SLICE, m->mapLen);
     if (m->failed.load()) return;
-    if (!m->noFallocate && fallocate(m->fd, 0, (off_t)b, (off_t)(e - b)) != 0) {
-        // no room (or a quota): touching the mapping would end in SIGBUS -- from here on this file is written with pwrite,
-        // which reports the error.  Anything else: a file system without fallocate, the populate below does the allocation.
-        if (errno == ENOSPC || errno == EDQUOT || errno == EFBIG) { m->failed = true; return; }
-        m->noFallocate = true;
+    // the pages are allocated by ONE thread per file that runs ahead (falloc_worker: concurrent fallocate calls on one file are
+    // slower than one, 7 against 19 GB/s); a slice it will not reach (beyond the pre-fault range, or no such thread) is
+    // allocated here
+    while (!m->noFallocate.load() && !m->failed.load() && m->fallocDone.load() < e) {
+        if (m->fallocRunning.load() && e <= m->preEnd.load()) { usleep(200); continue; }
+        if (fallocate(m->fd, 0, (off_t)b, (off_t)(e - b)) != 0) {
+            if (errno == ENOSPC || errno == EDQUOT || errno == EFBIG) { m->failed = true; return; }
+            m->noFallocate = true;
+        }
+        break;
     }
+    if (m->failed.load()) return;
+    PopSlot slot;
 #ifdef MADV_POPULATE_WRITE
     if (madvise(m->map + b, (size_t)(e - b), MADV_POPULATE_WRITE) != 0) {
         if (errno == ENOMEM || errno == EFAULT || errno == ENOSPC) { m->failed = true; return; }   // (EFAULT: the fault would have been a SIGBUS)
@@ -336,6 +351,27 @@ static void populate_slice(bfq_outmap *m, uint64_t idx)
     }
 #endif
     m->done += e - b;
+}
+// allocates (and zeroes) the file's pages from the front, 128 MiB per call
+static void falloc_worker(bfq_outmap *m)
+{
+    const uint64_t STEP = 128ull << 20;
+    for (uint64_t b = 0;;) {
+        if (m->stop.load(std::memory_order_relaxed) || m->failed.load()) break;
+        if (bfq_env().prefaultPause && g_bfqUploadsRunning.load(std::memory_order_relaxed) > 0) { usleep(500); continue; }
+        const uint64_t pe = m->preEnd.load();
+        if (b >= pe) break;
+        const uint64_t e = std::min<uint64_t>(b + STEP, std::min<uint64_t>(pe + PF_SLICE, m->mapLen));
+        if (fallocate(m->fd, 0, (off_t)b, (off_t)(e - b)) != 0) {
+            // no room (or a quota): touching the mapping would end in SIGBUS -- from here on this file is written with pwrite,
+            // which reports the error.  Anything else: a file system without fallocate, the populate does the allocation.
+            if (errno == ENOSPC || errno == EDQUOT || errno == EFBIG) m->failed = true; else m->noFallocate = true;
+            break;
+        }
+        m->fallocDone = e;
+        b = e;
+    }
+    m->fallocRunning = false;
 }
 static void prefault_worker(bfq_outmap *m)
 {
@@ -391,11 +427,12 @@ bfq_outmap *bfq_outmap_open(int fd, uint64_t map_len, uint64_t prefault_len)
     const uint64_t pe0 = m->preEnd.load();
     int T = bfq_env().prefaultThreads;
     if (T < 0) {
-        T = bfq_cpu_budget() >= 16 ? 3 : bfq_cpu_budget() >= 8 ? 2 : 1;
+        T = bfq_cpu_budget() >= 8 ? 2 : 1;                       // (+ the thread that allocates ahead of them)
     }
     if (pe0 < (64ull << 20)) T = 0;                              // small outputs: not worth a thread
     m->alive = T;
     m->tOpen = now_s();
+    if (T) { m->fallocRunning = true; m->fallocThread = std::thread(falloc_worker, m); }
     for (int t = 0; t < T; t++) m->th.emplace_back(prefault_worker, m);
     return m;
 }
@@ -416,6 +453,7 @@ bool bfq_outmap_close(bfq_outmap *m, uint64_t final_len)
 {
     if (!m) return true;
     m->stop = true;
+    if (m->fallocThread.joinable()) m->fallocThread.join();
     for (auto &t : m->th) if (t.joinable()) t.join();
     if (bfq_env().trace)
         fprintf(stderr, "[bfq io] output mapping %.2f GB: %.2f GB prepared (fallocate + populate), %zu helper thread(s) done %.3f s after the file was opened (closed after %.3f s)\n",

@@ -259,10 +259,10 @@ struct ClusterRank { const u64 *rankBlk; u64 F[6]; u8 *qual, *repl; };
 void bfq_clusters(bfq_ctx *c, const RankIndex &R, const u8 *bwt, const u8 *qual, const u8 *in, u64 n, const ClusterPos *pm = nullptr,
                   const ClusterRank *rm = nullptr);
 // steps 2-4 on a given eBWT without the LF table (k_compact.hip): rank blocks + qualities in place + replacement array
-#define BFQ_COMPACT_LCP_WIN (64ull << 20)                 // rows of the LCP file in flight
-size_t bfq_ws_need_compact(bfq_ctx *c, u64 n, u64 N, u64 extra, bool haveLcp);
+#define BFQ_COMPACT_LCP_WIN (256ull << 20)                // rows of the LCP file in flight (one upload by all staging workers)
+size_t bfq_ws_need_compact(bfq_ctx *c, u64 n, u64 N, u64 extra, bool haveLcp, size_t resident);   // resident: the caller's eBWT + qualities
 void bfq_steps234_compact(bfq_ctx *c, const u8 *bwt, u8 *qual, HostRef lcp, int lcp_bytes, u64 n, u64 N, u64 *d_roff, u32 *lens,
-                          u8 *ob, u8 *oq);
+                          u8 **ob, u8 **oq, u64 extra, size_t resident);
 // LF walks: lengths only, then emission at given offsets
 void bfq_invert_count(bfq_ctx *c, const RankIndex &R, u64 N, u32 *lens);
 void bfq_fixed_offsets(bfq_ctx *c, u64 N, u64 L, u64 *d_roff);   // d_roff[i] = i * L, i <= N

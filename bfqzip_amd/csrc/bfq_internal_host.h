@@ -29,7 +29,9 @@ struct BfqEnv {
     char abOrder[8] = {0};          // BFQ_AB_ORDER=<permutation of 0123>: the order of A.w12, A.w0, B.w0, B.w12 in the arena (placement experiments)
     bool abSwap = false;            // BFQ_AB_SWAP=1: the second record buffer below the first (placement experiments)
     bool compact = false;           // BFQ_COMPACT=1: steps 2-4 on a given eBWT + LCP without the LF table whatever the cap (k_compact.hip; test knob)
+    unsigned long long compactRing = 0; // BFQ_COMPACT_RING: entries of the interval refinement's ring queue there (default: what the cap leaves; small values test the chunked levels / the move to host memory)
     unsigned long long compactWin = 0;  // BFQ_COMPACT_WIN: rows of the LCP file in flight there (default 64 Mi; small values test the windowing)
+    bool prefaultPause = false;     // BFQ_PREFAULT_PAUSE=1: output files are not allocated while an input file is being read (default: both at once)
     bool noOutmap = false;          // BFQ_NO_OUTMAP: the tools write their outputs with pwrite instead of through a mapping (test knob)
     int invertNt = 1;               // BFQ_INVERT_NT=0: plain instead of nontemporal LF-table loads in k_invert
 };

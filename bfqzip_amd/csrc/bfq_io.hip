@@ -28,12 +28,13 @@ static int io_threads()
 {
     static const int t = [] {
         { int v = bfq_env().ioThreads; if (v >= 1 && v <= BFQ_IO_MAX_WORKERS) return v; }
-        // staging workers beside the main thread (idle while they run), the populate helpers and the runtime's own
-        // threads: three quarters of the budget.  More workers than a local memcpy needs: when the page-cache pages of a
-        // file another process wrote lie on the other socket a worker moves 1 GB/s, not 4 (first reads of a fresh 9.5 GB
-        // input: 8-12 GB/s with 8 workers, 30 GB/s once local)
+        // staging workers beside the main thread, the threads that prepare the output files (one fallocate + two populate
+        // per tool) and the runtime's own: 6 of a budget of 16.  6 workers move 30-38 GB/s when they have their CPUs; 12
+        // (three quarters of a cgroup quota of 16) put the process over its quota together with the helpers, and every
+        // phase paid: tools at 30 M x 150, gsufsort / bfq_int wall, three runs each -- 12 workers 2.77 3.17 2.77 / 5.62 3.82
+        // 3.00 s, 6 workers 2.73 2.87 2.36 / 2.75 3.16 2.33 s (profiles/r3/dropin_phases.md)
         const int cpus = bfq_cpu_budget();
-        return cpus >= 16 ? 12 : cpus >= 8 ? 5 : cpus >= 4 ? 2 : 1;
+        return cpus >= 16 ? 6 : cpus >= 8 ? 4 : cpus >= 4 ? 2 : 1;
     }();
     return t;
 }
@@ -121,8 +122,10 @@ static bool host_put(const HostRef &h, size_t off, const char *src, size_t sz)
 static bool io_trace() { return bfq_env().trace; }
 static double now_s() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
 
+extern std::atomic<int> g_bfqUploadsRunning;                   // bfq_host.cpp: the output helpers stand back meanwhile
 static void staged_copy(bfq_ctx *c, char *dev, HostRef host, size_t len, bool up)
 {
+    struct Busy { bool on; Busy(bool o) : on(o) { if (on) g_bfqUploadsRunning++; } ~Busy() { if (on) g_bfqUploadsRunning--; } } busy(up && !host.ptr);
     const double t0 = io_trace() ? now_s() : 0;
     // one worker per 128 MiB (each costs two pinned 16 MiB buffers the first time): a 200 MB file is not worth sixteen of them
     const int want = (int)std::min<size_t>(BFQ_IO_MAX_WORKERS, (len + (128u << 20) - 1) / (128u << 20));

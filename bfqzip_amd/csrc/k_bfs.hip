@@ -46,8 +46,9 @@ struct BfsArgs {
     const u64 *rank;        // [n/64 + 2][8]
     u64 F[6];               // first row of every symbol's suffixes (# A C G N T)
     u16 *lcp;               // [n + 1]
-    u64 *queue;             // [n + 64]; ring mode (qmask != 0): [qmask + 1], positions taken modulo its size
-    u64 qmask;
+    u64 *queue;             // [n + 64]; ring mode (qsize != 0): [qsize], positions taken modulo its size
+    u64 qsize;
+    u64 qlimit;             // log mode: positions below this one have an entry to be stored to
     u64 *tail;              // [0] next free queue slot, [1] / [2] lengths of the two side lists, [3] LCP entries written, [4] fill list length
     u64 *side[2];           // long intervals (lb, rb | leaf) of the current / next level
     u64 sideCap;
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
         bool leaf = false;
         if (valid) {
             if (SIDE) { lb = a.side[cur][2 * i]; rb = a.side[cur][2 * i + 1]; leaf = (rb & BQ_LEAF) != 0; rb &= ~BQ_LEAF; }
-            else { const u64 e = __builtin_nontemporal_load(a.queue + (a.qmask ? ((qbeg + i) & a.qmask) : qbeg + i)); lb = e & BQ_LB_MASK; rb = lb + ((e >> BQ_LB_BITS) & BQ_LEN_MAX); leaf = (e & BQ_LEAF) != 0; }
+            else { const u64 e = __builtin_nontemporal_load(a.queue + (a.qsize ? (qbeg + i) % a.qsize : qbeg + i)); lb = e & BQ_LB_MASK; rb = lb + ((e >> BQ_LB_BITS) & BQ_LEN_MAX); leaf = (e & BQ_LEAF) != 0; }
         }
         u32 nkids = 0;
         u64 kid[5];                                                // packed children to enqueue
@@ -177,9 +178,10 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
             // (a byte sequence that is no eBWT can enqueue more than the n intervals a real one has: the stores stop at the
             // queue's end, the host sees the tail beyond it and reports BFQ_E_NOT_EBWT)
             for (u32 j = threadIdx.x; j < used; j += 256) {
-                // ring: never onto an entry of the level being read (they start at qbeg); what does not fit is dropped and flagged
-                if (a.qmask) { if (sBase + j - qbeg <= a.qmask) __builtin_nontemporal_store(stage[j], a.queue + ((sBase + j) & a.qmask)); else a.tail[5] = 1; }
-                else if (sBase + j < a.n + 64) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+                // ring: never onto an unread entry (they start at qbeg; the host launches only as many parents as have room for
+                // five children each, so the flag is an assertion)
+                if (a.qsize) { if (sBase + j - qbeg < a.qsize) __builtin_nontemporal_store(stage[j], a.queue + (sBase + j) % a.qsize); else a.tail[5] = 1; }
+                else if (sBase + j < a.qlimit) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
             }
             __syncthreads();
             used = 0;
@@ -192,8 +194,8 @@ __global__ __launch_bounds__(256) void k_bfs_level(BfsArgs a, u64 qbeg, u64 qend
         if (threadIdx.x == 0) sBase = atomicAdd((unsigned long long *)&a.tail[0], (unsigned long long)used);
         __syncthreads();
         for (u32 j = threadIdx.x; j < used; j += 256) {
-            if (a.qmask) { if (sBase + j - qbeg <= a.qmask) __builtin_nontemporal_store(stage[j], a.queue + ((sBase + j) & a.qmask)); else a.tail[5] = 1; }
-            else if (sBase + j < a.n + 64) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
+            if (a.qsize) { if (sBase + j - qbeg < a.qsize) __builtin_nontemporal_store(stage[j], a.queue + (sBase + j) % a.qsize); else a.tail[5] = 1; }
+            else if (sBase + j < a.qlimit) __builtin_nontemporal_store(stage[j], a.queue + sBase + j);
         }
     }
     const u64 wsum = bfq_readlane64(bfq_wave_incscan64(written), 63);
@@ -246,8 +248,12 @@ void bfq_rank_blocks(bfq_ctx *c, const u8 *bwt, u64 n, int term, const u64 *scan
 
 // lcp[0..n): LCP array of the eBWT `bwt` (device, n rows, N of them terminators).  Workspace: n bytes of rank blocks,
 // 8 n bytes of queue (released on return).  rankGiven: the rank blocks exist already (and the symbol totals are in
-// c->h_cnt); ringEntries != 0: the queue is a ring of that many entries (a power of two) instead of a log of n -- only the
-// current level and the one being written are live; a level too wide for it is an error (k_compact.hip, under a cap).
+// c->h_cnt).  ringEntries != 0 (k_compact.hip, under a cap): the queue is a ring of that many entries instead of a log of n.
+// Only the unread part of the level being read and the level being written are live.  A level is then launched in chunks:
+// as many parents as the free entries hold five children for (an interval has at most five); when they are done their
+// slots are free.  Two consecutive levels that do not fit the ring at all (little coverage: most LCP values lie within a few
+// levels of log4 n) move the queue to pinned host memory -- the kernels read and write it there, 16 bytes per interval
+// over the link -- rather than fail.
 void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lcp, u32 *gcntOut, const u64 *rankGiven, u64 ringEntries)
 {
     if (!n) return;
@@ -267,34 +273,82 @@ void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lc
         for (int s = 0; s < 6; s++) { a.F[s] = acc; acc += c->h_cnt.tot[s]; }
         if (acc != n || c->h_cnt.tot[0] != N) throw BfqError{BFQ_E_NOT_EBWT, "symbol counts do not add up to the eBWT"};
     }
+    if (ringEntries && ringEntries < 64) ringEntries = 64;
+    if (ringEntries >= n + 64) ringEntries = 0;                    // as large as the log: be the log
     a.rank = rank; a.lcp = lcp; a.n = n;
-    a.qmask = ringEntries ? ringEntries - 1 : 0;
+    a.qsize = ringEntries; a.qlimit = n + 64;
     a.queue = c->alloc<u64>(ringEntries ? ringEntries : n + 64);
     a.tail = c->alloc<u64>(8);
     a.sideCap = (n >> BQ_LEN_BITS) + 16;
     a.side[0] = c->alloc<u64>(2 * a.sideCap); a.side[1] = c->alloc<u64>(2 * a.sideCap);
     a.fillCap = n / (BQ_FILL_INLINE + 1) + 16;                     // listed blocks are disjoint and hold more than BQ_FILL_INLINE rows each
     a.fill = c->alloc<u64>(2 * a.fillCap);
+    struct HostQueue { u64 *p = nullptr; ~HostQueue() { if (p) (void)hipHostFree(p); } } hostQ;
     HIP_CHECK(hipMemsetAsync(lcp, 0xFF, 2 * (n + 1), c->stream));
     KLAUNCH(c, K_BFS, 2.0 * (double)N, k_bfs_init, bfq_grid(N + 1, 256), 256, a, N);
     u64 t[6] = {0, 0, 0, 0, 0, 0};
-    HIP_CHECK(hipMemcpyAsync(t, a.tail, 48, hipMemcpyDeviceToHost, c->stream));
-    c->sync();
+    auto fetch = [&] {
+        HIP_CHECK(hipMemcpyAsync(t, a.tail, 48, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    };
+    fetch();
     u64 qbeg = 0, qend = t[0], nside = t[2];
     int cur = 1;
+    u32 chunksMax = 1;
+    // ring -> log in pinned host memory; [from, t[0]) are the live entries
+    auto to_host = [&](u64 from, u32 level) {
+        const u64 live = t[0] - from, room = live + (n - (t[3] < n ? t[3] : n)) + 1024;   // every further entry writes an LCP value
+        void *hp = nullptr;
+        if (hipHostMalloc(&hp, room * 8, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            throw BfqError{BFQ_E_NOMEM, "interval refinement: two levels do not fit the queue the workspace cap leaves room for, nor pinned host memory; raise bfq_params.ws_cap_mib / BFQ_WS_CAP"};
+        }
+        hostQ.p = (u64 *)hp;
+        for (u64 o = from; o < t[0];) {
+            const u64 ri = o % a.qsize, len = (t[0] - o < a.qsize - ri) ? t[0] - o : a.qsize - ri;
+            HIP_CHECK(hipMemcpyAsync(hostQ.p + (o - from), a.queue + ri, len * 8, hipMemcpyDeviceToHost, c->stream));
+            o += len;
+        }
+        c->sync();
+        void *dp = nullptr;
+        HIP_CHECK(hipHostGetDevicePointer(&dp, hp, 0));
+        if (bfq_env().trace)
+            fprintf(stderr, "[bfq] interval refinement: level %u holds %llu intervals, the ring %llu: queue moved to %.2f GB of pinned host memory\n",
+                    level, (unsigned long long)live, (unsigned long long)a.qsize, room * 8 / 1e9);
+        a.queue = (u64 *)((uintptr_t)dp - (uintptr_t)from * 8);    // indexed by absolute position from here on
+        a.qsize = 0; a.qlimit = from + room;
+    };
+    auto check = [&] {
+        if (t[0] > n + 32 || t[0] + 32 > a.qlimit || t[1 + (cur ^ 1)] > a.sideCap || t[4] > a.fillCap)
+            throw BfqError{BFQ_E_NOT_EBWT, "interval refinement overran the eBWT: not a BWT"};
+        if (t[5]) throw BfqError{BFQ_E_NOMEM, "interval refinement: ring queue overrun"};
+    };
     for (u32 level = 1; qend > qbeg || nside; level++) {
         if (level > BFQ_MAX_READ_LEN + 2) throw BfqError{BFQ_E_TOO_LONG, "LCP beyond BFQ_MAX_READ_LEN (or not an eBWT)"};
         HIP_CHECK(hipMemsetAsync(a.tail + 1 + (cur ^ 1), 0, 8, c->stream));
         // per interval: two 64-B rank blocks, per child one LCP probe + store, 8 B of queue in and out
-        if (qend > qbeg)
-            KLAUNCH(c, K_BFS, 160.0 * (double)(qend - qbeg), k_bfs_level<false>, bfq_grid(qend - qbeg, 256 * 8), 256, a, qbeg, qend, level, cur);
-        if (nside) KLAUNCH(c, K_BFS, 0.0, k_bfs_level<true>, bfq_grid(nside, 256), 256, a, qbeg, qend, level, cur);
-        HIP_CHECK(hipMemcpyAsync(t, a.tail, 48, hipMemcpyDeviceToHost, c->stream));
-        c->sync();
-        if (t[0] > n + 32 || t[1 + (cur ^ 1)] > a.sideCap || t[4] > a.fillCap)
-            throw BfqError{BFQ_E_NOT_EBWT, "interval refinement overran the eBWT: not a BWT"};
-        if (ringEntries && t[5])                                   // this level + the next one did not fit the ring: children were dropped
-            throw BfqError{BFQ_E_NOMEM, "interval refinement: a level wider than the queue the workspace cap leaves room for; raise bfq_params.ws_cap_mib / BFQ_WS_CAP"};
+        u64 pb = qbeg;
+        if (a.qsize) {
+            const u64 sideRoom = 5 * nside;                        // the long intervals of the side list are extended last
+            if (a.qsize - (t[0] - pb) < sideRoom) to_host(pb, level);
+            u32 chunks = 0;
+            while (a.qsize && pb < qend) {
+                const u64 rem = qend - pb, room = a.qsize - (t[0] - pb) - sideRoom;
+                u64 chunk = room / 5;
+                if (chunk < rem && chunk < (rem / 64 > 4096 ? rem / 64 : 4096)) { to_host(pb, level); break; }   // (not in a crawl)
+                if (chunk > rem) chunk = rem;
+                KLAUNCH(c, K_BFS, 160.0 * (double)chunk, k_bfs_level<false>, bfq_grid(chunk, 256 * 8), 256, a, pb, pb + chunk, level, cur);
+                pb += chunk;
+                if (pb < qend) { fetch(); check(); }
+                chunks++;
+            }
+            if (chunks > chunksMax) chunksMax = chunks;
+        }
+        if (qend > pb)
+            KLAUNCH(c, K_BFS, 160.0 * (double)(qend - pb), k_bfs_level<false>, bfq_grid(qend - pb, 256 * 8), 256, a, pb, qend, level, cur);
+        if (nside) KLAUNCH(c, K_BFS, 0.0, k_bfs_level<true>, bfq_grid(nside, 256), 256, a, qend, qend, level, cur);
+        fetch();
+        check();
         if (t[4]) {
             KLAUNCH(c, K_BFS, 0.0, k_bfs_fill, (unsigned)(t[4] < 4096 ? t[4] : 4096), 256, a, t[4], level);
             HIP_CHECK(hipMemsetAsync(a.tail + 4, 0, 8, c->stream));
@@ -303,7 +357,11 @@ void bfq_lcp_from_bwt(bfq_ctx *c, const u8 *bwt, u64 n, u64 N, int term, u16 *lc
         nside = t[1 + (cur ^ 1)];
         cur ^= 1;
     }
+    if (bfq_env().trace && ringEntries)
+        fprintf(stderr, "[bfq] interval refinement: ring of %llu entries for %llu rows, at most %u launches per level%s\n",
+                (unsigned long long)ringEntries, (unsigned long long)n, chunksMax, hostQ.p ? ", finished in host memory" : "");
     // every LCP entry 1..n is written exactly once
     if (t[3] != n) throw BfqError{BFQ_E_NOT_EBWT, "interval refinement does not cover the eBWT: not a BWT of a read collection"};
+    c->sync();
     c->release(mk);
 }

@@ -96,28 +96,37 @@ static u64 lcp_window(bfq_ctx *c, u64 n)
     if (W > n) W = n;
     return W ? W : 1;
 }
-// entries of the interval refinement's ring queue (bfq_int mode under a cap): a power of two, an eighth of the rows or more
-static u64 ring_entries(u64 n)
+// What the arena holds: rank blocks, flags, replacements (3 n) for the whole call; then either the LCP scratch (bfq_ext: a
+// window of the LCP file; bfq_int: the 16-bit LCP, the refinement's ring queue and lists) or, once the flags exist, the
+// reads going out (2 n).  The ring takes what the cap leaves (the caller's eBWT + qualities, `resident` bytes, count too):
+// a sixteenth of the rows at least, the n entries of the plain log at most.
+static size_t compact_fixed(u64 n, u64 N, u64 extra)
 {
-    u64 r = 1u << 16;
-    while (r < n / 8) r <<= 1;
-    return r;
+    return 3 * (n + 1024) + 72 * (n / 256 + 2) + 16 * (N + 64) + extra + (96u << 20);
 }
-size_t bfq_ws_need_compact(bfq_ctx *c, u64 n, u64 N, u64 extra, bool haveLcp)
+static size_t compact_lcp_lists(u64 n) { return 2 * (n + 256) + 32 * (n / 65 + 64) + 64 * ((n >> 25) + 64) + 65536; }
+static u64 ring_entries(bfq_ctx *c, u64 n, u64 N, u64 extra, size_t resident)
 {
-    size_t need = 0;
-    need += 3 * (n + 1024) + 72 * (n / 256 + 2);                // rank blocks, flags, replacements; symbol counts / scans
-    need += 2 * (n + 256) + 16 * (N + 64);                      // reads out, offsets / lengths
-    if (haveLcp) need += (size_t)(lcp_window(c, n) + 4) * 6 + (n >> 20) * 64 + 4096;
-    else need += 2 * (n + 256) + 8 * ring_entries(n) + 32 * (n / 65 + 64) + 64 * ((n >> 25) + 64);   // 16-bit LCP, ring queue, fill / side lists
-    need += extra + (96u << 20);
-    return need;
+    if (c->env.compactRing) return c->env.compactRing;
+    u64 lo = n / 16 > 65536 ? n / 16 : 65536, hi = n + 64;
+    if (!c->wsLimit()) return hi;
+    const size_t used = compact_fixed(n, N, extra) + compact_lcp_lists(n) + resident;
+    const u64 fit = c->wsLimit() > used ? (c->wsLimit() - used) / 8 : 0;
+    return fit < lo ? lo : fit > hi ? hi : fit;
+}
+size_t bfq_ws_need_compact(bfq_ctx *c, u64 n, u64 N, u64 extra, bool haveLcp, size_t resident)
+{
+    const size_t out = 2 * (n + 256);                           // reads out
+    size_t lcp;
+    if (haveLcp) lcp = (size_t)(lcp_window(c, n) + 4) * 6 + (n >> 20) * 64 + 4096;
+    else lcp = compact_lcp_lists(n) + 8 * (size_t)ring_entries(c, n, N, extra, resident);
+    return compact_fixed(n, N, extra) + (lcp > out ? lcp : out);
 }
 
 // bwt / qual: the given eBWT and its permuted qualities on the device (qual is edited in place); lcp: the LCP file / array
 // (lcp_bytes 1, 2 or 4 per entry).  Leaves the reads in ob / oq (packed) and their offsets in d_roff.
 void bfq_steps234_compact(bfq_ctx *c, const u8 *bwt, u8 *qual, HostRef lcp, int lcp_bytes, u64 n, u64 N, u64 *d_roff, u32 *lens,
-                          u8 *ob, u8 *oq)
+                          u8 **obOut, u8 **oqOut, u64 extra, size_t resident)
 {
     c->n = n; c->N = N;
     const u64 ngroups = n / 256 + 1;
@@ -140,7 +149,7 @@ void bfq_steps234_compact(bfq_ctx *c, const u8 *bwt, u8 *qual, HostRef lcp, int 
         // lives only until the flags are made
         const size_t mk = c->mark();
         u16 *lcp16 = c->alloc<u16>(n + 64);
-        bfq_lcp_from_bwt(c, bwt, n, N, c->P.term & 0xFF, lcp16, nullptr, rank, ring_entries(n));
+        bfq_lcp_from_bwt(c, bwt, n, N, c->P.term & 0xFF, lcp16, nullptr, rank, ring_entries(c, n, N, extra, resident));
         bfq_lcp_flags(c, lcp16, n, c->P.K, in);
         c->sync();
         c->release(mk);
@@ -162,6 +171,8 @@ void bfq_steps234_compact(bfq_ctx *c, const u8 *bwt, u8 *qual, HostRef lcp, int 
         }
         c->release(mk);
     }
+    u8 *ob = c->alloc<u8>(n - N + 64), *oq = c->alloc<u8>(n - N + 64);   // (where the LCP scratch was)
+    *obOut = ob; *oqOut = oq;
     ClusterRank rm;
     rm.rankBlk = rank; rm.qual = qual; rm.repl = repl;
     for (int s = 0; s < 6; s++) rm.F[s] = R.F[s];

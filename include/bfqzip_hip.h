@@ -52,7 +52,9 @@ typedef struct bfq_params {
     int32_t ws_cap_mib; /* upper bound of the device workspace in MiB, 0 = none ($BFQ_WS_CAP in bytes, suffixes K/M/G, overrides it).
                        What a block needs: 28.6 n bytes in one piece, 13 n pile by pile; below that the capped mode runs it in
                        ~8 n: two-symbol piles one at a time, edits written to the text position of every row, no eBWT-sized
-                       array, no LF table, no inversion -- same bytes out, about twice the time              */
+                       array, no LF table, no inversion -- same bytes out, about a third more time.  Steps 2-4
+                       on a GIVEN eBWT (bfq_smooth_invert*: 17 n with the LF table) then run on 64-byte rank blocks answered
+                       on demand, qualities edited in place and a replacement array: 7 n (LCP given) / 9 n (deduced)          */
     int32_t reserved[5];
 } bfq_params;
 

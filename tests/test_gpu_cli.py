@@ -133,6 +133,17 @@ def test_tools_on_files_beyond_one_staging_chunk(tools, tmp_path, engine):
     want = engine.smooth_invert_fastq(np.fromfile(out + "e.bwt", np.uint8), qs, lcp=lcp.astype(np.uint32))[0]
     engine.set_params()
     assert np.fromfile(out + "x.fq", np.uint8).tobytes() == want
+    # the same tools under a workspace cap (BFQ_WS_CAP): steps 2-4 without the LF table (k_compact.hip), same files
+    capenv = dict(os.environ, BFQ_WS_CAP="1100M", BFQ_COMPACT_WIN="4M", BFQ_TRACE="1")
+    engine.set_params(m=5)
+    want_int = engine.smooth_invert_fastq(bwt, qs)[0]
+    engine.set_params()
+    r = _run([tools["bfq_int"], "-e", out + ".bwt", "-q", out + ".bwt.qs", "-o", out + ".cap.fq", "-m", "5"], env=capenv)
+    assert r.returncode == 0 and np.fromfile(out + ".cap.fq", np.uint8).tobytes() == want_int, r.stdout[-600:]
+    ws = [float(x) for x in __import__("re").findall(rb"workspace ([0-9.]+) GiB", r.stdout)]
+    assert ws and max(ws) <= 1100 / 1024 + 0.01, r.stdout[-600:]
+    r = _run([tools["bfq_ext"], "-e", out + "e.bwt", "-q", out + "e.bwt.qs", "-a", out + "e.4.lcp", "-o", out + "xc", "-l", "250", "-s", "0", "-m", "5"], env=capenv)
+    assert r.returncode == 0 and np.fromfile(out + "xc.fq", np.uint8).tobytes() == want, r.stdout[-600:]
     # outputs that cannot be mapped go through pwrite (BFQ_NO_OUTMAP forces that route); no helper threads at all
     for env in (dict(BFQ_NO_OUTMAP="1"), dict(BFQ_PREFAULT_THREADS="0")):
         r = _run([tools["gsufsort"], fq, "--bwt", "--qs", "-o", out + "n"], env=dict(os.environ, **env))

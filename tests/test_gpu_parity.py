@@ -300,7 +300,12 @@ def test_compact_steps_on_a_given_ebwt(engine, orc, monkeypatch):
             assert np.array_equal(gb, eb) and np.array_equal(gq, eq) and np.array_equal(groff, eroff), (ci, par, dt)
             for k in est:
                 assert est[k] == gst[k], (k, ci, par)
-        ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)            # bfq_int mode
+        # bfq_int mode; every other case with a ring of 64 entries: levels in chunks, then the queue in host memory
+        if ci % 2:
+            monkeypatch.setenv("BFQ_COMPACT_RING", "64")
+            engine.set_params(**full)                                 # (the environment is read when parameters are set)
+        ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)
+        monkeypatch.delenv("BFQ_COMPACT_RING", raising=False)
         assert np.array_equal(ib, eb) and np.array_equal(iq, eq) and np.array_equal(iroff, eroff), (ci, par)
         for k in est:
             assert est[k] == ist[k], (k, ci, par)
@@ -325,6 +330,14 @@ def test_compact_steps_on_a_given_ebwt(engine, orc, monkeypatch):
     ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)
     assert engine.workspace_bytes() <= 2600 << 20
     assert np.array_equal(ib, fb) and np.array_equal(iq, fq_) and np.array_equal(iroff, froff) and ist == fst
+    # rings smaller than a level and its children (the default takes what the cap leaves): levels launched in chunks as
+    # their parents' slots come free (n / 5), the queue moved to host memory when two levels do not fit at all (n / 40)
+    for div in (5, 40):
+        monkeypatch.setenv("BFQ_COMPACT_RING", str(len(bwt) // div))
+        engine.set_params(m=5, M=1, B=1, ws_cap_mib=2600)
+        ib, iq, iroff, ist = engine.smooth_invert(bwt, qs)
+        assert np.array_equal(ib, fb) and np.array_equal(iq, fq_) and np.array_equal(iroff, froff) and ist == fst, div
+    monkeypatch.delenv("BFQ_COMPACT_RING")
     engine.set_params(m=5, ws_cap_mib=400)
     with pytest.raises(api.BfqError) as e:
         engine.smooth_invert(bwt, qs, lcp)
