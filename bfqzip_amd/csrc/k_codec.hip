@@ -305,7 +305,7 @@ __global__ __launch_bounds__(256) void k_cdc_checksum(const u8 *__restrict__ in,
     if ((threadIdx.x & 63) == 0 && sum) atomicAdd((unsigned long long *)out, (unsigned long long)sum);
 }
 // d_tmp: 8 bytes of device scratch
-static u64 cdc_checksum_device(bfq_ctx *c, const u8 *d_in, u64 n, u64 *d_tmp)
+u64 bfq_codec_checksum_device(bfq_ctx *c, const u8 *d_in, u64 n, u64 *d_tmp)
 {
     HIP_CHECK(hipMemsetAsync(d_tmp, 0, 8, c->stream));
     if (n) KLAUNCH(c, K_CODEC, (double)n, k_cdc_checksum, bfq_grid((n + 7) / 8, 256 * 16), 256, d_in, n, d_tmp);
@@ -370,21 +370,27 @@ static u64 get64(const u8 *p) { return (u64)get32(p) | ((u64)get32(p + 4) << 32)
 u64 bfq_codec_bound(u64 n)
 {
     const u64 nseg = (n + 1023) / 1024;
-    return 32 + CQ_HDR + 256 + 512 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64;
+    // (+ n / 2: a BFQDNAC1 container holds a second, small BFQRANS2 container -- the line lengths -- in front of its payload)
+    return 32 + CQ_HDR + 256 + 512 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64 + n / 2 + (16u << 20);
 }
+u64 bfq_dnac_workspace(u64 n);                                                                   // k_dnac.hip
+u64 bfq_dnac_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap);
+u64 bfq_dnac_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap);
+u64 bfq_dnac_member_len(const u8 *h_in, u64 len);
 // device workspace of one compress / decompress call
 u64 bfq_codec_workspace(u64 n)
 {
     const u64 nseg = (n + 1023) / 1024;
     // + the line-delta transform of streams with 8 .. 128 bytes per line: line index, prefix lengths, record sizes / offsets, the records
-    return n + bfq_codec_bound(n) + nseg * (u64)CQ_SLOT(1024) + 16ull * CQ_MAX_TABLE + 24 * nseg + 4 * n + (64u << 20);
+    // + the context table of the read-order DNA container (k_dnac.hip; its per-base arrays fit what the line transform counts)
+    return n + bfq_codec_bound(n) + nseg * (u64)CQ_SLOT(1024) + 16ull * CQ_MAX_TABLE + 24 * nseg + 4 * n + (64u << 20) + bfq_dnac_workspace(n);
 }
 
 // d_in: n raw bytes on the device.  The container goes to d_out (capacity cap); returns its length.
-static u64 rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
+u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
 {
     const size_t mk = c->mark();
-    const u64 checksum = cdc_checksum_device(c, d_in, n, c->alloc<u64>(1));
+    const u64 checksum = bfq_codec_checksum_device(c, d_in, n, c->alloc<u64>(1));
     u32 *d_present = c->alloc<u32>(256);
     HIP_CHECK(hipMemsetAsync(d_present, 0, 1024, c->stream));
     if (n) KLAUNCH(c, K_CODEC, (double)n, k_cdc_present, bfq_grid(n, 256 * 64), 256, d_in, n, d_present);
@@ -516,6 +522,7 @@ static void cdc_parse(const u8 *in, u64 len, CdcHeader &H)
 // Length of the first member / raw length of all members.
 u64 bfq_codec_member_len(const u8 *h_in, u64 len)
 {
+    if (len >= 8 && !memcmp(h_in, "BFQDNAC1", 8)) return bfq_dnac_member_len(h_in, len);
     if (len >= 32 && !memcmp(h_in, "BFQLINE1", 8)) return 32 + bfq_codec_member_len(h_in + 32, len - 32);
     CdcHeader H;
     cdc_parse(h_in, len, H);
@@ -527,7 +534,7 @@ u64 bfq_codec_raw_len(const u8 *h_in, u64 len)
 {
     u64 pos = 0, raw = 0;
     do {
-        const bool lx = len - pos >= 32 && !memcmp(h_in + pos, "BFQLINE1", 8);
+        const bool lx = (len - pos >= 32 && !memcmp(h_in + pos, "BFQLINE1", 8)) || (len - pos >= 72 && !memcmp(h_in + pos, "BFQDNAC1", 8));
         if (!lx && (len - pos < CQ_HDR + 256 || memcmp(h_in + pos, "BFQRANS2", 8))) throw BfqError{BFQ_E_ARG, "not a BFQRANS2 stream"};
         raw += get64(h_in + pos + 8);
         pos += bfq_codec_member_len(h_in + pos, len - pos);
@@ -537,7 +544,7 @@ u64 bfq_codec_raw_len(const u8 *h_in, u64 len)
 
 // h_in: the whole container on the host (its header is parsed there), d_in: the same bytes on the device.
 // The raw bytes go to d_out (capacity cap); returns their number.
-static u64 rans_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap)
+u64 bfq_rans_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap)
 {
     CdcHeader H;
     cdc_parse(h_in, len, H);
@@ -571,7 +578,7 @@ static u64 rans_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u6
     u32 bad = 0;
     HIP_CHECK(hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
     c->sync();
-    const u64 sum = bad ? 0 : cdc_checksum_device(c, d_out, m.n, c->alloc<u64>(1));
+    const u64 sum = bad ? 0 : bfq_codec_checksum_device(c, d_out, m.n, c->alloc<u64>(1));
     c->release(mk);
     if (bad) throw BfqError{BFQ_E_ARG, "damaged BFQRANS2 stream"};
     if (sum != get64(h_in + 36)) throw BfqError{BFQ_E_ARG, "damaged BFQRANS2 stream (checksum of the decoded bytes)"};
@@ -678,19 +685,23 @@ static u64 line_xform_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 **d_T, u64 *n
 // d_in: n raw bytes on the device.  The container goes to d_out (capacity cap); returns its length.
 u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
 {
+    {   // read-order DNA: its own container (k_dnac.hip); 0 = the stream is something else
+        const u64 got = bfq_dnac_compress_device(c, d_in, n, d_out, cap);
+        if (got) return got;
+    }
     const size_t mk = c->mark();
     u8 *d_T = nullptr;
     u64 nl = 0;
     const u64 xl = line_xform_device(c, d_in, n, &d_T, &nl);
     u64 got;
-    if (!xl) got = rans_compress_device(c, d_in, n, d_out, cap);
+    if (!xl) got = bfq_rans_compress_device(c, d_in, n, d_out, cap);
     else {
         if (cap < 32) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
         u8 h[32];
         memcpy(h, "BFQLINE1", 8); put64(h + 8, n); put32(h + 16, CQ_LINE_R); put32(h + 20, 0); put64(h + 24, nl);
         HIP_CHECK(hipMemcpyAsync(d_out, h, 32, hipMemcpyHostToDevice, c->stream));
         c->sync();
-        got = 32 + rans_compress_device(c, d_T, xl, d_out + 32, cap - 32);
+        got = 32 + bfq_rans_compress_device(c, d_T, xl, d_out + 32, cap - 32);
     }
     c->release(mk);
     return got;
@@ -700,7 +711,8 @@ u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 
 // The raw bytes go to d_out (capacity cap); returns their number.
 u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap)
 {
-    if (len < 32 || memcmp(h_in, "BFQLINE1", 8)) return rans_decompress_device(c, h_in, d_in, len, d_out, cap);
+    if (len >= 8 && !memcmp(h_in, "BFQDNAC1", 8)) return bfq_dnac_decompress_device(c, h_in, d_in, len, d_out, cap);
+    if (len < 32 || memcmp(h_in, "BFQLINE1", 8)) return bfq_rans_decompress_device(c, h_in, d_in, len, d_out, cap);
     const BfqError bad{BFQ_E_ARG, "damaged BFQLINE1 stream"};
     const u64 n = get64(h_in + 8), nl = get64(h_in + 24);
     if (n > cap || get32(h_in + 16) != CQ_LINE_R || nl < 2 || nl > n) throw bad;
@@ -709,7 +721,7 @@ u64 bfq_codec_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 
     if (xl > n + nl) throw bad;
     const size_t mk = c->mark();
     u8 *d_T = c->alloc<u8>(xl + 16);
-    if (rans_decompress_device(c, h_in + 32, d_in + 32, len - 32, d_T, xl) != xl) throw bad;
+    if (bfq_rans_decompress_device(c, h_in + 32, d_in + 32, len - 32, d_T, xl) != xl) throw bad;
     u64 nrec = 0;
     const u64 *recEnd = bfq_line_index(c, d_T, xl, &nrec);
     if (nrec != nl) throw bad;

@@ -28,9 +28,42 @@ def cases():
             cur = int(jumps[i])
         q[i] = 40 + cur
     out["runs_20_symbols"] = q
+    # read-order DNA (lines of ACGTN): the BFQDNAC1 container when the stream is 64 KiB or more, lines of 15 bases or more
+    # on average, none beyond 65535 -- else BFQRANS2
+    out["reads_30x"] = reads(rng, 20000, 30, 100)
+    out["reads_var_len"] = reads(rng, 6000, 40, 120, var=True)                   # lengths 0..120, empty lines among them
+    out["reads_below_64k"] = reads(rng, 2000, 30, 100)[:101 * 640]
+    out["reads_short_lines"] = reads(rng, 6000, 40, 12, var=True)                # 6 bases per line on average: not this container
+    out["reads_n_runs"] = reads(rng, 4000, 25, 150, n_runs=True)
+    long_line = rng.choice(np.frombuffer(b"ACGT", np.uint8), 65535)
+    out["reads_line_65535"] = np.concatenate([reads(rng, 3000, 10, 100), long_line, np.array([10], np.uint8), reads(rng, 3000, 10, 100)])
+    out["reads_line_65536"] = np.concatenate([reads(rng, 3000, 10, 100), long_line, np.array([65, 10], np.uint8)])
     # headers
     out["headers"] = np.frombuffer(b"".join(b"@SYN.%d\n" % i for i in range(30000)), np.uint8).copy()
     return out
+
+
+def reads(rng, G, cov, L, var=False, n_runs=False, err=0.01, n_rate=0.001):
+    """cov-fold coverage of a random genome of G bases by reads of L bases from both strands, one per line."""
+    g = rng.integers(0, 4, G).astype(np.uint8)
+    comp = np.array([3, 2, 1, 0], np.uint8)
+    letters = np.frombuffer(b"ACGT", np.uint8)
+    out = []
+    for _ in range(G * cov // max(L, 1)):
+        l = int(rng.integers(0, L + 1)) if var else L
+        p = int(rng.integers(0, G - L))
+        s = g[p:p + l].copy()
+        if rng.integers(0, 2):
+            s = comp[s][::-1].copy()
+        e = rng.random(l) < err
+        s[e] = (s[e] + rng.integers(1, 4, int(e.sum()))) % 4
+        s = letters[s].copy()
+        s[rng.random(l) < n_rate] = ord("N")
+        if n_runs and rng.integers(0, 10) == 0 and l > 40:
+            a = int(rng.integers(0, l - 30))
+            s[a:a + int(rng.integers(1, 30))] = ord("N")
+        out.append(s.tobytes() + b"\n")
+    return np.frombuffer(b"".join(out), np.uint8).copy()
 
 
 def sampled_case():

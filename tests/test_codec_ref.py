@@ -17,6 +17,13 @@ PINNED = {
     "period4": (1444, "a95d8384fc56cc26b581983201712529"),
     "random_bytes": (51862, "32abd53a601caad662bde30ac9e35ea7"),
     "runs_20_symbols": (69625, "e7b21da3a85beb627d8e585d19fab6ff"),
+    "reads_30x": (52312, "68b0618c5263138740d1aafcb4739342"),
+    "reads_below_64k": (18194, "6013d67bbb0a09805cb47dcfc81cadaa"),
+    "reads_line_65535": (35037, "9bbfc840451e5be89bce246ce9496060"),
+    "reads_line_65536": (27086, "00f8be0321d9aa3c51f3b57b744d308d"),
+    "reads_n_runs": (10754, "7347a2d68ffd6d69fbd36f2ad178861d"),
+    "reads_short_lines": (52158, "8d2898ee9965e2d728225b1f171a5e7f"),
+    "reads_var_len": (19100, "e66711b21d0392e044e572a830420284"),
     "seg_exact": (9342, "3faa94554ed0c1bc77d6584a80c7135b"),
     "seg_minus_1": (9342, "7eec4f6ce3e2e6a6e50e4fcec05c1218"),
     "seg_plus_1": (9342, "836ef8819a3ea51f2810f50368c1ddd8"),
@@ -113,3 +120,32 @@ def test_checksum_and_damage_are_noticed():
     b4 = blob.copy(); b4[len(blob) - 3000:len(blob) - 500] = 0      # more than one whole segment of zeros
     with pytest.raises(RuntimeError):
         orc.codec_decode(b4)
+
+
+def test_read_order_dna_container():
+    """BFQDNAC1 (block-adaptive hashed context model): what it is chosen for, what it must refuse."""
+    c = cases()
+    for name, kind in (("reads_30x", b"BFQDNAC1"), ("reads_var_len", b"BFQDNAC1"), ("reads_n_runs", b"BFQDNAC1"), ("reads_line_65535", b"BFQDNAC1"),
+                       ("reads_below_64k", b"BFQRANS2"), ("reads_short_lines", b"BFQRANS2"), ("reads_line_65536", b"BFQRANS2"), ("dna_like", b"BFQRANS2")):
+        assert orc.codec_encode(c[name])[:8].tobytes() == kind, name
+    data = c["reads_30x"]
+    blob = orc.codec_encode(data).copy()
+    assert 8 * len(blob) < 0.8 * len(data)                          # 30x coverage: well under one bit per base (static order-k model: 2.0)
+    # members of both kinds back to back
+    both = np.concatenate([blob, orc.codec_encode(c["headers"]), orc.codec_encode(c["reads_var_len"])])
+    assert (orc.codec_decode(both) == np.concatenate([data, c["headers"], c["reads_var_len"]])).all()
+    # damage: header fields, the lengths' container, payload bytes, zeroed segments, a cut
+    rng = np.random.default_rng(5)
+    for pos in (0, 9, 17, 25, 32, 36, 44, 52, 56, 64, 72 + 40, 72 + 400):
+        bad = blob.copy(); bad[pos] ^= 1
+        with pytest.raises(RuntimeError):
+            orc.codec_decode(bad)
+    for _ in range(30):
+        bad = blob.copy(); bad[int(rng.integers(len(blob) - 20000, len(blob)))] ^= int(rng.integers(1, 256))
+        with pytest.raises(RuntimeError):
+            orc.codec_decode(bad)
+    bad = blob.copy(); bad[len(blob) - 9000:len(blob) - 300] = 0
+    with pytest.raises(RuntimeError):
+        orc.codec_decode(bad)
+    with pytest.raises(RuntimeError):
+        orc.codec_decode(blob[:len(blob) - 100])

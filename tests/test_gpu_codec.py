@@ -57,7 +57,7 @@ def test_job_with_compressed_streams(engine):
     assert z.stats == plain.stats and np.array_equal(z.fastq, plain.fastq)
     for a, b in ((z.dna, plain.dna), (z.qs, plain.qs), (z.hdr, plain.hdr)):
         a = np.asarray(a)
-        assert bytes(a[:8]) in (b"BFQRANS2", b"BFQLINE1") and len(a) < len(b)
+        assert bytes(a[:8]) in (b"BFQRANS2", b"BFQLINE1", b"BFQDNAC1") and len(a) < len(b)
         assert np.array_equal(np.asarray(engine.stream_decompress(a)), np.asarray(b))
         assert np.array_equal(orc.codec_encode(np.asarray(b)), a)
     # two parts (paired blocks): the containers cover the whole collection
@@ -200,6 +200,52 @@ def test_refuses_damaged_streams(engine):
     z = qs.copy(); z[len(qs) - 6000:len(qs) - 200] = 0
     with pytest.raises(api.BfqError):
         engine.stream_decompress(z)
+
+
+def test_read_order_dna_container(engine):
+    """BFQDNAC1 on the GPU (k_dnac.hip): chosen for the same streams as the CPU statement chooses it for (the byte equality
+    is test_container_equals_cpu_statement's and test_pipeline_streams'); members of both kinds back to back; damage to header
+    fields, the lengths' container, payload bytes, zeroed segments and a cut are all refused; BFQ_DNA_STATIC=1 keeps the static
+    container; a 2 M-read stream (more than one block of 65536 segments... at this size 64 blocks) round trips."""
+    c = cases()
+    data = c["reads_30x"]
+    blob = np.asarray(engine.stream_compress(data)).copy()
+    assert blob[:8].tobytes() == b"BFQDNAC1" and 8 * len(blob) < 0.8 * len(data)
+    both = np.concatenate([blob, np.asarray(engine.stream_compress(c["headers"])), np.asarray(engine.stream_compress(c["reads_var_len"]))])
+    assert (np.asarray(engine.stream_decompress(both)) == np.concatenate([data, c["headers"], c["reads_var_len"]])).all()
+    rng = np.random.default_rng(5)
+    for pos in (0, 9, 17, 25, 32, 36, 44, 52, 56, 64, 72 + 40, 72 + 400):
+        bad = blob.copy(); bad[pos] ^= 1
+        with pytest.raises(api.BfqError):
+            engine.stream_decompress(bad)
+    for _ in range(20):
+        bad = blob.copy(); bad[int(rng.integers(len(blob) - 20000, len(blob)))] ^= int(rng.integers(1, 256))
+        with pytest.raises(api.BfqError):
+            engine.stream_decompress(bad)
+    bad = blob.copy(); bad[len(blob) - 9000:len(blob) - 300] = 0
+    with pytest.raises(api.BfqError):
+        engine.stream_decompress(bad)
+    with pytest.raises(api.BfqError):
+        engine.stream_decompress(blob[:len(blob) - 100])
+    os.environ["BFQ_DNA_STATIC"] = "1"
+    try:
+        engine.set_params()                                         # (the environment is read when parameters are set)
+        st = np.asarray(engine.stream_compress(data))
+        assert st[:8].tobytes() == b"BFQRANS2" and len(st) > 2 * len(blob)
+        assert (np.asarray(engine.stream_decompress(st)) == data).all()
+    finally:
+        del os.environ["BFQ_DNA_STATIC"]
+        engine.set_params()
+    sp = api.synth_spec(2_000_000, 100, seed=3)
+    text = np.empty(2_000_000 * 260, np.uint8)
+    n = engine.synth_fastq(sp, text)
+    engine.set_params(m=5)
+    r = engine.fastq_job([text[:n]], fastq=False, streams=True)
+    raw = np.asarray(r.dna)
+    z = np.asarray(engine.stream_compress(raw))
+    assert z[:8].tobytes() == b"BFQDNAC1" and 8 * len(z) < 0.8 * len(raw)
+    assert (np.asarray(engine.stream_decompress(z)) == raw).all()
+    engine.set_params()
 
 
 def test_bsc_front_end(tmp_path):
