@@ -405,7 +405,7 @@ class Engine:
         blob = _u8(blob)
         n = int(self.L.bfq_stream_raw_len(_ptr(blob), len(blob)))
         if n < 0:
-            raise BfqError(-1, "not a BFQRANS2 stream")
+            raise BfqError(-1, "not a BFQRANS2 / BFQDNAC1 / BFQLINE1 stream")
         if out is None:
             out = np.empty(max(n, 1), np.uint8)
         ol = C.c_uint64(0)

@@ -53,7 +53,7 @@ int main(int argc, char **argv)
     if (enc) cap = bfq_stream_bound(in.size());
     else {
         const int64_t raw = bfq_stream_raw_len(in.data(), in.size());
-        if (raw < 0) { fprintf(stderr, "bsc: %s is not a BFQRANS2 stream\n", argv[2]); bfq_destroy(c); return 1; }
+        if (raw < 0) { fprintf(stderr, "bsc: %s is not a BFQRANS2 / BFQDNAC1 / BFQLINE1 stream\n", argv[2]); bfq_destroy(c); return 1; }
         cap = (uint64_t)raw;
     }
     std::vector<uint8_t> out(cap ? cap : 1);
@@ -63,7 +63,7 @@ int main(int argc, char **argv)
     if (rc) { fprintf(stderr, "bsc: %s\n", bfq_last_error(c)); bfq_destroy(c); return 1; }
     bfq_destroy(c);
     if (!write_file(argv[3], out.data(), got)) { fprintf(stderr, "bsc: cannot write %s\n", argv[3]); return 1; }
-    if (enc) printf("%s compressed %llu into %llu in BFQRANS2 (GPU static order-k model + rANS)\n", argv[2], (unsigned long long)in.size(), (unsigned long long)got);
+    if (enc) printf("%s compressed %llu into %llu (GPU context model + rANS: BFQDNAC1 / BFQRANS2 / BFQLINE1)\n", argv[2], (unsigned long long)in.size(), (unsigned long long)got);
     else printf("%s decompressed %llu into %llu\n", argv[2], (unsigned long long)in.size(), (unsigned long long)got);
     return 0;
 }

@@ -374,7 +374,7 @@ u64 bfq_codec_bound(u64 n)
     return 32 + CQ_HDR + 256 + 512 + CQ_MAX_TABLE / 8 + 2ull * CQ_MAX_TABLE + 4 * nseg + n + n / 2 + 8 * nseg + 64 + n / 2 + (16u << 20);
 }
 u64 bfq_dnac_workspace(u64 n);                                                                   // k_dnac.hip
-u64 bfq_dnac_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap);
+u64 bfq_dnac_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap, u64 *nbases);
 u64 bfq_dnac_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap);
 u64 bfq_dnac_member_len(const u8 *h_in, u64 len);
 // device workspace of one compress / decompress call
@@ -387,7 +387,8 @@ u64 bfq_codec_workspace(u64 n)
 }
 
 // d_in: n raw bytes on the device.  The container goes to d_out (capacity cap); returns its length.
-u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
+// dry: only the container's length is wanted (nothing is written to d_out)
+u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap, bool dry)
 {
     const size_t mk = c->mark();
     const u64 checksum = bfq_codec_checksum_device(c, d_in, n, c->alloc<u64>(1));
@@ -436,7 +437,7 @@ u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 c
         for (u32 s = 0; s < A; s++) { cum[x * A + s] = (u16)acc; acc += freq[x * A + s]; }
     }
     const u64 hdr = CQ_HDR + 256 + 2ull * A + used.size() + nused * A * 2 + 4ull * m.nseg;
-    if (hdr > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
+    if (hdr > cap && !dry) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
     std::vector<u32> fcv(E);
     for (u64 x = 0; x < E; x++) fcv[x] = (u32)freq[x] | ((u32)cum[x] << 16);
     u32 *d_fc = c->alloc<u32>(E);
@@ -453,10 +454,12 @@ u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 c
         HIP_CHECK(hipMemcpyAsync(&total, d_total, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_CHECK(hipMemcpyAsync(segBytes.data(), d_segBytes, 4ull * m.nseg, hipMemcpyDeviceToHost, c->stream));
         c->sync();
+        if (dry) { c->release(mk); return hdr + total; }
         if (hdr + total > cap) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
         KLAUNCH(c, K_CODEC, 2.0 * (double)total, k_cdc_pack, bfq_grid((u64)m.nseg * 64, 256), 256, (const u8 *)scratch, (const u32 *)d_segBytes,
                 (const u64 *)d_off, m.nseg, m.seg, d_out + hdr);
     }
+    if (dry) { c->release(mk); return hdr + total; }
     std::vector<u8> h(hdr);
     u8 *p = h.data();
     memcpy(p, "BFQRANS2", 8); put64(p + 8, n);
@@ -686,22 +689,25 @@ static u64 line_xform_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 **d_T, u64 *n
 u64 bfq_codec_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
 {
     {   // read-order DNA: its own container (k_dnac.hip); 0 = the stream is something else
-        const u64 got = bfq_dnac_compress_device(c, d_in, n, d_out, cap);
-        if (got) return got;
+        u64 nbases = 0;
+        const u64 got = bfq_dnac_compress_device(c, d_in, n, d_out, cap, &nbases);
+        // little coverage leaves the table nothing to learn: above 1.6 bits per base the smaller of this and the plain static container
+        if (got && (5 * got <= nbases || bfq_rans_compress_device(c, d_in, n, d_out, cap, true) >= got)) return got;
+        if (got) return bfq_rans_compress_device(c, d_in, n, d_out, cap, false);
     }
     const size_t mk = c->mark();
     u8 *d_T = nullptr;
     u64 nl = 0;
     const u64 xl = line_xform_device(c, d_in, n, &d_T, &nl);
     u64 got;
-    if (!xl) got = bfq_rans_compress_device(c, d_in, n, d_out, cap);
+    if (!xl) got = bfq_rans_compress_device(c, d_in, n, d_out, cap, false);
     else {
         if (cap < 32) throw BfqError{BFQ_E_ARG, "output buffer too small for the compressed stream"};
         u8 h[32];
         memcpy(h, "BFQLINE1", 8); put64(h + 8, n); put32(h + 16, CQ_LINE_R); put32(h + 20, 0); put64(h + 24, nl);
         HIP_CHECK(hipMemcpyAsync(d_out, h, 32, hipMemcpyHostToDevice, c->stream));
         c->sync();
-        got = 32 + bfq_rans_compress_device(c, d_T, xl, d_out + 32, cap - 32);
+        got = 32 + bfq_rans_compress_device(c, d_T, xl, d_out + 32, cap - 32, false);
     }
     c->release(mk);
     return got;

@@ -92,7 +92,9 @@ void bfq_rank_blocks(bfq_ctx *c, const u8 *bwt, u64 n, int term, const u64 *scan
 
 static u64 lcp_window(bfq_ctx *c, u64 n)
 {
+    // (up to a third of the rows the window's 6 bytes per row lie where the reads go out later: it costs no workspace)
     u64 W = c->env.compactWin ? c->env.compactWin : BFQ_COMPACT_LCP_WIN;
+    if (!c->env.compactWin && W > n / 3) W = n / 3 > (1u << 20) ? n / 3 : (1u << 20);
     if (W > n) W = n;
     return W ? W : 1;
 }

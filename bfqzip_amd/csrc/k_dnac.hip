@@ -32,7 +32,7 @@
 #define DQ_MAXLINE 65535u
 #define DQ_SLOT(cnt) (2ull * (cnt) + 16ull)          // scratch bytes of a segment of cnt symbols (a symbol costs at most 12 bits)
 
-u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap);                        // k_codec.hip
+u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap, bool dry);              // k_codec.hip
 u64 bfq_rans_decompress_device(bfq_ctx *c, const u8 *h_in, const u8 *d_in, u64 len, u8 *d_out, u64 cap);
 u64 bfq_codec_checksum_device(bfq_ctx *c, const u8 *d_in, u64 n, u64 *d_tmp);
 
@@ -405,19 +405,20 @@ static DqPar dq_default_par(bfq_ctx *c, u64 nbases)
 }
 
 // d_in: n raw bytes on the device.  Returns the container's length, 0 when the container does not apply to the stream.
-u64 bfq_dnac_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap)
+u64 bfq_dnac_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 cap, u64 *nbasesOut)
 {
     const size_t mk = c->mark();
     DqMem M(c);
     DqInput I;
     if (!dq_prepare(c, M, d_in, n, I)) { c->release(mk); return 0; }
+    *nbasesOut = I.nbases;
     const BfqError small{BFQ_E_ARG, "output buffer too small for the compressed stream"};
     const u64 nseg = (I.nbases + DQ_S - 1) / DQ_S;
     if (nseg > 0xFFFFFFFFull || cap < DQ_HDR) throw small;
     const DqPar Pm = dq_default_par(c, I.nbases);
     const u32 H = Pm.H;
     const u64 checksum = bfq_codec_checksum_device(c, d_in, n, M.get<u64>(1));
-    const u64 ll = bfq_rans_compress_device(c, (const u8 *)I.lens, 4 * I.nreads, d_out + DQ_HDR, cap - DQ_HDR);
+    const u64 ll = bfq_rans_compress_device(c, (const u8 *)I.lens, 4 * I.nreads, d_out + DQ_HDR, cap - DQ_HDR, false);
     const u64 hdr = DQ_HDR + ll + 4 * nseg;
     if (hdr > cap) throw small;
     u64 *T = M.get<u64>(1ull << H);

@@ -288,9 +288,12 @@ int bfq_synth_fastq(bfq_ctx *c, const bfq_synth *s, uint8_t *h_out, uint64_t cap
  * Replaces step 5 of the reference, which hands every stream to an external tool: `7z a -mm=PPMd <f>.7z <f>`
  * (step5, BFQzip.py:253-263) or `external/libbsc/bsc e <f> <f>.bsc -T` (step5b, BFQzip.py:265-275).  The front-end
  * dropin/external/libbsc/bsc takes that command line (`bsc e IN OUT [options]`, `bsc d IN OUT`).
- * The container ("BFQRANS2": static order-k model + range-ANS, segments of 8192 symbols) is this project's own --
- * neither 7z nor libbsc are part of the reference tree -- and is stated in oracle/bfq_codec_ref.c.
- * Any bytes compress (the model adapts to the alphabet it finds); host buffers in and out. */
+ * The containers are this project's own -- neither 7z nor libbsc are part of the reference tree -- and are stated in
+ * oracle/bfq_codec_ref.c: "BFQRANS2" (any bytes: static order-k model + range-ANS, segments of 8192 symbols), "BFQLINE1"
+ * (read names: a line-delta transform in front of it) and "BFQDNAC1" (read-order DNA, lines of A C G T N: a hashed
+ * order-K context model that adapts block by block, rebuilt by the decoder from what it has decoded; a third of the static
+ * container's size at 30x coverage, a quarter of its speed; $BFQ_DNA_STATIC=1 keeps the static one).
+ * Any bytes compress; host buffers in and out.  bfq_stream_decompress takes containers of any kind back to back. */
 uint64_t bfq_stream_bound(uint64_t len);                          /* capacity that always suffices for `len` raw bytes */
 int64_t  bfq_stream_raw_len(const uint8_t *h_in, uint64_t len);   /* raw length of a container, -1 if it is not one  */
 int bfq_stream_compress(bfq_ctx *c, const uint8_t *h_in, uint64_t len, uint8_t *h_out, uint64_t cap, uint64_t *out_len);

@@ -17,7 +17,8 @@
  * READ-ORDER DNA (OUT.fq.dna: lines of A C G T N, every one ending with '\n') takes the BFQDNAC1 container below when the
  * stream is nothing else: the redundancy of a 30x collection is between reads that cover the same stretch of the genome, 16
  * and more symbols of context away from what an order-7 table sees (2.06 bits per base); streams of 64 KiB and more only,
- * lines of 15 bases or more on average and none beyond 65535.  What PPMd / bsc do with an adaptive
+ * lines of 15 bases or more on average and none beyond 65535; and when the result is above 1.6 bits per base (little coverage:
+ * nothing to learn from) and the plain BFQRANS2 container of the same bytes is smaller, that one is the output.  What PPMd / bsc do with an adaptive
  * model, symbol by symbol, is done here block by block so that both directions stay parallel:
  *   bases   = the lines without their '\n' (symbols A 0, C 1, G 2, T 3, N 4); lens[i] = length of line i (u32)
  *   segment g = the reads whose first base has an index in [g S, (g+1) S) of `bases` (S = 1024; a segment may be empty)
@@ -629,7 +630,18 @@ static uint64_t line_xform(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t
 int64_t orc_codec_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap)
 {
     uint64_t nl = 0;
-    if (dnac_applies(in, n, &nl)) return dnac_encode(in, n, nl, out, cap);
+    if (dnac_applies(in, n, &nl)) {
+        /* little coverage (a sample of a large genome) leaves the context table nothing to learn and its chance hits cost:
+         * above 1.6 bits per base the plain static container is made as well, and the smaller of the two is the output */
+        const int64_t r = dnac_encode(in, n, nl, out, cap);
+        if (r < 0 || 5 * (uint64_t)r <= n - nl) return r;
+        uint8_t *t = (uint8_t *)malloc(cap);
+        if (!t) return -2;
+        const int64_t r2 = rans_encode(in, n, t, cap);
+        if (r2 >= 0 && r2 < r) memcpy(out, t, (size_t)r2);
+        free(t);
+        return (r2 >= 0 && r2 < r) ? r2 : r;
+    }
     const uint64_t xl = line_xform(in, n, NULL, &nl);
     if (!xl || xl * 4 > n * 3) return rans_encode(in, n, out, cap);
     if (cap < 32) return -1;

@@ -19,8 +19,9 @@ PINNED = {
     "runs_20_symbols": (69625, "e7b21da3a85beb627d8e585d19fab6ff"),
     "reads_30x": (52312, "68b0618c5263138740d1aafcb4739342"),
     "reads_below_64k": (18194, "6013d67bbb0a09805cb47dcfc81cadaa"),
-    "reads_line_65535": (35037, "9bbfc840451e5be89bce246ce9496060"),
-    "reads_line_65536": (27086, "00f8be0321d9aa3c51f3b57b744d308d"),
+    "reads_line_65535": (34628, "f67eb72b63841215bb996fb53d754b0f"),
+    "reads_line_65536": (27158, "a9fc6fa57bb6cb85d8202f5b30526ed6"),
+    "reads_low_coverage": (1127146, "dd115392b9f9b7e48bafb1f70d9ea4a8"),
     "reads_n_runs": (10754, "7347a2d68ffd6d69fbd36f2ad178861d"),
     "reads_short_lines": (52158, "8d2898ee9965e2d728225b1f171a5e7f"),
     "reads_var_len": (19100, "e66711b21d0392e044e572a830420284"),
@@ -126,7 +127,7 @@ def test_read_order_dna_container():
     """BFQDNAC1 (block-adaptive hashed context model): what it is chosen for, what it must refuse."""
     c = cases()
     for name, kind in (("reads_30x", b"BFQDNAC1"), ("reads_var_len", b"BFQDNAC1"), ("reads_n_runs", b"BFQDNAC1"), ("reads_line_65535", b"BFQDNAC1"),
-                       ("reads_below_64k", b"BFQRANS2"), ("reads_short_lines", b"BFQRANS2"), ("reads_line_65536", b"BFQRANS2"), ("dna_like", b"BFQRANS2")):
+                       ("reads_below_64k", b"BFQRANS2"), ("reads_low_coverage", b"BFQRANS2"), ("reads_short_lines", b"BFQRANS2"), ("reads_line_65536", b"BFQRANS2"), ("dna_like", b"BFQRANS2")):
         assert orc.codec_encode(c[name])[:8].tobytes() == kind, name
     data = c["reads_30x"]
     blob = orc.codec_encode(data).copy()
