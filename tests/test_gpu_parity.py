@@ -496,8 +496,13 @@ def test_full_size_properties(engine):
     import time as _t
     for label, l in (("bfq_ext", lcp), ("bfq_int", None)):
         engine.set_params(k=16, m=5, M=2, B=0, v=ord(">"), ws_cap_mib=40 * 1024)
-        t0 = _t.perf_counter(); cb, cq, croff, cst = engine.smooth_invert(bwt, qs, l); dtc = _t.perf_counter() - t0
-        print(f"compact steps 2-4 ({label} job), 30 M x 150 under 40 GiB: workspace {engine.workspace_bytes() / 2**30:.1f} GiB, {dtc * 1e3:.0f} ms host arrays to host arrays")
+        # timed on the second call: the first one's allocation waits for the driver to scrub the 77 GiB the uncapped call
+        # before it has just given back (freed HBM is cleared at ~30 GB/s and the next allocation waits for it)
+        dts = []
+        for _ in range(2):
+            t0 = _t.perf_counter(); cb, cq, croff, cst = engine.smooth_invert(bwt, qs, l); dts.append(_t.perf_counter() - t0)
+        dtc = dts[1]
+        print(f"compact steps 2-4 ({label} job), 30 M x 150 under 40 GiB: workspace {engine.workspace_bytes() / 2**30:.1f} GiB, {dtc * 1e3:.0f} ms host arrays to host arrays (first call, incl. the wait for scrubbed memory: {dts[0] * 1e3:.0f} ms)")
         assert engine.workspace_bytes() <= 40 * 2**30
         assert {k: cst[k] for k in ("num_clust", "qs_smoothed", "modified")} == {k: st[k] for k in ("num_clust", "qs_smoothed", "modified")}
         assert np.array_equal(cb, ib) and np.array_equal(cq, iq) and np.array_equal(croff, iroff)
