@@ -305,12 +305,18 @@ def global_mode(api, parallel, eng, text, N, L, dna_ref, qs_ref, log):
             for o in range(0, len(mv), 1 << 30):
                 f.write(mv[o:o + (1 << 30)])
         names = parallel.output_names([d + "/in.fastq"], d + "/G", False)
-        t0 = time.perf_counter()
-        tot = parallel.run_global(eng, parallel.Comm(), [d + "/in.fastq"], names, want_fastq=False, want_streams=True)
-        dt = time.perf_counter() - t0
+        runs = []
+        for it in range(2):                                      # best of two, as e2e_host is the best of its iterations: a first run
+            for nm in names[0].values():                         # pays for device allocations that land on memory the driver has not
+                if os.path.exists(nm):                           # cleared yet ("text exchange" 0.03 or 0.5 s at one rank)
+                    os.unlink(nm)
+            t0 = time.perf_counter()
+            tot = parallel.run_global(eng, parallel.Comm(), [d + "/in.fastq"], names, want_fastq=False, want_streams=True)
+            runs.append((time.perf_counter() - t0, tot))
+        dt, tot = min(runs, key=lambda r: r[0])
         same = bool(np.array_equal(np.fromfile(names[0]["dna"], np.uint8), dna_ref) and np.array_equal(np.fromfile(names[0]["qs"], np.uint8), qs_ref))
-        log(f"global mode: {dt:.2f}s {tot['seconds']} parity={same}")
-        return {"wall_s": round(dt, 3), "Mbases_per_s": round(N * L / 1e6 / dt, 1), "seconds": tot["seconds"], "streams_equal_fused_path": same,
+        log(f"global mode: {dt:.2f}s (runs: {[round(r[0], 2) for r in runs]}) {tot['seconds']} parity={same}")
+        return {"wall_s": round(dt, 3), "runs_s": [round(r[0], 3) for r in runs], "Mbases_per_s": round(N * L / 1e6 / dt, 1), "seconds": tot["seconds"], "streams_equal_fused_path": same,
                 "what": "parallel.run_global, 1 rank: file on /dev/shm -> upload, parse, text, 25 piles sorted one by one, position-mode clusters, "
                         "streams written to /dev/shm; compared with e2e_host's streams"}
     except Exception as e:

@@ -30,6 +30,37 @@ static thread_local std::string g_createErr;
 // The arena can also be built from physically contiguous chunks mapped into one address range (HIP's virtual memory
 // management: BFQ_WS_VMM=<chunk MiB>): what the 512 write streams of a radix pass cost depends on how the range is backed
 // (placement experiments).
+void bfq_ctx::reserveBegin(size_t bytes)
+{
+    bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
+    if (wsThread || bytes <= wsCap || env.wsVmmMib || env.wsContig || (wsLimit() && bytes > wsLimit())) return;
+    wsPendBytes = bytes; wsPend = nullptr;
+    const int dev = device;
+    wsThread = new std::thread([this, dev, bytes] {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        void *p = nullptr;
+        if (hipSetDevice(dev) != hipSuccess || hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); p = nullptr; }
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        wsPend = (char *)p;
+        wsPendSecs = (t1.tv_sec - t0.tv_sec) + 1e-9 * (t1.tv_nsec - t0.tv_nsec);
+    });
+}
+// adopt: the pending arena replaces the current one when it holds `need` bytes (and the current one does not)
+void bfq_ctx::reserveJoin(bool adopt, size_t need)
+{
+    if (!wsThread) return;
+    wsThread->join();
+    delete wsThread;
+    wsThread = nullptr;
+    if (!wsPend) return;
+    if (adopt && need <= wsPendBytes && need > wsCap && !(wsLimit() && wsPendBytes > wsLimit())) {
+        wsFree();
+        ws = wsPend; wsCap = wsPendBytes; wsTop = 0;
+        if (bfq_env().trace) fprintf(stderr, "[bfq] workspace %.1f GiB: hipMalloc %.3f s, beside the upload\n", wsCap / 1073741824.0, wsPendSecs);
+    } else (void)hipFree(wsPend);
+    wsPend = nullptr; wsPendBytes = 0;
+}
 void bfq_ctx::wsFree()
 {
     if (!ws) return;
@@ -85,6 +116,7 @@ static hipError_t ws_alloc_vmm(bfq_ctx *c, size_t bytes, size_t chunk, char **ou
 void bfq_ctx::reserve(size_t bytes)
 {
     bytes = (bytes + 0xFFFFF) & ~(size_t)0xFFFFF;
+    reserveJoin(true, bytes);
     if (wsLimit() && bytes > wsLimit()) {
         char b[200];
         snprintf(b, sizeof b, "device workspace of %.1f GiB is above the cap of %.1f GiB (bfq_params.ws_cap_mib / BFQ_WS_CAP)", bytes / 1073741824.0, wsLimit() / 1073741824.0);
@@ -847,6 +879,11 @@ static void smooth_invert_core(bfq_ctx *c, HostRef h_bwt, HostRef h_bwtqs, HostR
         if (haveLcp && lcp_bytes != 1 && lcp_bytes != 2 && lcp_bytes != 4) throw BfqError{BFQ_E_ARG, "lcp_bytes must be 1, 2 or 4"};
         const u64 npad = (n + 255) & ~255ull;
         bfq_phase("alloc");
+        // the arena of the table path, allocated beside the upload of the eBWT (its exact size needs the number of reads,
+        // which the upload is counted for: reads of 32 bases or more assumed, reserve() below allocates again when that was short)
+        if (!c->env.compact && n >= (64u << 20) && !c->env.noOverlap)
+            c->reserveBegin(ws_need_given(n, n / 32, extraWs + (haveLcp ? (size_t)lcp_bytes * n : 0)));
+        struct PendGuard { bfq_ctx *c; ~PendGuard() { c->reserveJoin(false, 0); } } pendGuard{c};
         u8 *in_bwt = c->textBuf(2 * npad + 256), *in_qs = in_bwt + npad;
         bfq_phase("read_h2d");
         bfq_upload(c, in_bwt, h_bwt, n);

@@ -7,6 +7,7 @@
 #include <functional>
 #include <string>
 #include <vector>
+#include <thread>
 #include "../../include/bfqzip_hip.h"
 #include "bfq_common.h"
 #include "bfq_internal_host.h"
@@ -74,6 +75,14 @@ struct bfq_ctx {
     size_t wsCap = 0, wsTop = 0;
     void reserve(size_t bytes);
     void wsFree();
+    // an arena being allocated on a helper thread while the caller uploads its input (a one-shot tool's 86 GB can land on
+    // memory the driver has not cleared yet: 2 s instead of 0); reserve() joins it and takes it over when it is large enough
+    void reserveBegin(size_t bytes);
+    void reserveJoin(bool adopt, size_t need);
+    std::thread *wsThread = nullptr;
+    char *wsPend = nullptr;
+    size_t wsPendBytes = 0;
+    double wsPendSecs = 0;
     size_t wsVmmChunk = 0;              // != 0: the arena is VMM chunks of this size mapped into one range (experiment)
     std::vector<void *> wsHandles;
     void dropWorkspace();           // frees the arena now (one-shot tools: lets the driver scrub it while outputs are written)
