@@ -350,6 +350,54 @@ static void cdc_normalise(const u32 *cnt, u32 A, u16 *f)
         f[best] = (u16)(f[best] + (M - sum));
     }
 }
+// (12 - log2 f) * 256 for a frequency f in 1 .. 4096, in integers (oracle/bfq_codec_ref.c: bit_cost)
+static u32 cdc_bit_cost(u32 f)
+{
+    u32 e = 0;
+    while ((2u << e) <= f) e++;
+    u64 m = (u64)f << (31 - e);
+    u32 frac = 0;
+    for (int i = 0; i < 8; i++) {
+        m = (m * m) >> 31;
+        frac <<= 1;
+        if (m >> 32) { frac |= 1; m >>= 1; }
+    }
+    return CQ_SCALE * 256 - (e * 256 + frac);
+}
+// The order the container is made with (oracle/bfq_codec_ref.c: choose_order): the counts were taken at order kmax; for every
+// order <= kmax the container's size is estimated (payload from the rows' normalised frequencies, times the sample step, + the
+// table) and the smallest wins.  cnt is left holding the counts of the chosen order.
+static u32 cdc_choose_order(std::vector<u32> &cnt, u32 A, u32 kmax, u32 S)
+{
+    u32 best = kmax;
+    u64 bestBits = ~0ull, nctx = 1;
+    for (u32 j = 0; j < kmax; j++) nctx *= A;
+    std::vector<u32> lvl(cnt.begin(), cnt.begin() + nctx * A), keep;
+    u16 f[256];
+    for (u32 k = kmax;; k--) {
+        u64 bits = 0, used = 0;
+        for (u64 x = 0; x < nctx; x++) {
+            u64 T = 0;
+            for (u32 s = 0; s < A; s++) T += lvl[x * A + s];
+            if (!T) continue;
+            used++;
+            cdc_normalise(lvl.data() + x * A, A, f);
+            for (u32 s = 0; s < A; s++) bits += (u64)lvl[x * A + s] * cdc_bit_cost(f[s]);
+        }
+        bits = bits / 256 * S + used * A * 16 + nctx;
+        if (bits < bestBits) { bestBits = bits; best = k; keep.assign(lvl.begin(), lvl.begin() + nctx * A); }
+        if (k == 0) break;
+        const u64 low = nctx / A;
+        for (u64 x = low; x < nctx; x++)
+            for (u32 s = 0; s < A; s++) {
+                const u64 v = (u64)lvl[(x % low) * A + s] + lvl[x * A + s];
+                lvl[(x % low) * A + s] = v > 0xFFFFFFFFull ? 0xFFFFFFFFu : (u32)v;
+            }
+        nctx = low;
+    }
+    std::copy(keep.begin(), keep.end(), cnt.begin());
+    return best;
+}
 static u32 cdc_choose_seg(u64 n)
 {
     u32 seg = CQ_SEG_MAX;
@@ -408,7 +456,7 @@ u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 c
     u64 nctx = 1;
     for (u32 j = 0; j < m.k; j++) nctx *= A;
     m.top = (u32)nctx;
-    const u64 E = nctx * A;
+    u64 E = nctx * A;
     u8 *d_map = c->alloc<u8>(256);
     HIP_CHECK(hipMemcpyAsync(d_map, map, 256, hipMemcpyHostToDevice, c->stream));
     u32 *d_cnt = c->alloc<u32>(E);
@@ -417,6 +465,11 @@ u64 bfq_rans_compress_device(bfq_ctx *c, const u8 *d_in, u64 n, u8 *d_out, u64 c
     std::vector<u32> cnt(E);
     HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, 4 * E, hipMemcpyDeviceToHost, c->stream));
     c->sync();
+    m.k = cdc_choose_order(cnt, A, m.k, step);                     // the counts were taken at the highest order considered
+    nctx = 1;
+    for (u32 j = 0; j < m.k; j++) nctx *= A;
+    m.top = (u32)nctx;
+    E = nctx * A;
     std::vector<u16> freq(E, 0), cum(E, 0);
     std::vector<u8> used((nctx + 7) / 8, 0);
     u64 nused = 0;

@@ -63,7 +63,9 @@
  *   u32   seg_bytes[nseg]
  *   u8    payload[]              the segments' rANS streams back to back
  * Context of a symbol = the k symbols before it INSIDE its segment (missing ones count as symbol 0), read as a base-A
- * number, oldest symbol most significant.  k = the largest order with A^(k+1) <= min(2^22, max(4096, sampled_len / 16)), at most 8.
+ * number, oldest symbol most significant.  k: counts are taken at the largest order kmax with A^(kmax+1) <= min(2^22,
+ * max(4096, sampled_len / 16)), at most 8; the container is made with the order <= kmax whose estimated size (payload + table,
+ * choose_order() below) is the smallest.
  * The model is counted on a SAMPLE: segments g with g % S == 0, S = clamp(raw_len / 2^24, 1, 64) (k is chosen for the
  * sampled length raw_len / S) -- a histogram of every symbol
  * of a 4.5 GB stream into a table of millions of bins is the one step that does not parallelise cheaply.  Every symbol of the
@@ -153,6 +155,63 @@ static void normalise(const uint32_t *cnt, uint32_t A, uint16_t *f)
     }
 }
 
+/* (12 - log2 f) * 256 for a frequency f in 1 .. 4096, in integers (the mantissa squared eight times) */
+static uint32_t bit_cost(uint32_t f)
+{
+    uint32_t e = 0;
+    while ((2u << e) <= f) e++;
+    uint64_t m = (uint64_t)f << (31 - e);                /* [2^31, 2^32) */
+    uint32_t frac = 0;
+    for (int i = 0; i < 8; i++) {
+        m = (m * m) >> 31;
+        frac <<= 1;
+        if (m >> 32) { frac |= 1; m >>= 1; }
+    }
+    return BQC_SCALE * 256 - (e * 256 + frac);
+}
+/* The order the container is made with: the counts were taken at order kmax; for every order k <= kmax (counts summed over the
+ * symbols that leave the context) the container's size is estimated -- sum count * cost of the row's normalised frequency,
+ * times the sample step, + 16 bits per table entry of a context that occurs + 1 bit per context -- and the smallest wins
+ * (the higher order among equals).  A table that costs more than it saves (short streams, data without structure at that
+ * depth: the DNA of a collection of little coverage) is not written.  cnt is left holding the counts of the chosen order. */
+static uint32_t choose_order(uint32_t *cnt, uint32_t A, uint32_t kmax, uint32_t S)
+{
+    uint32_t best = kmax;
+    uint64_t bestBits = ~0ull;
+    uint64_t nctx = 1;
+    for (uint32_t j = 0; j < kmax; j++) nctx *= A;
+    uint32_t *lvl = (uint32_t *)malloc(nctx * A * 4), *keep = (uint32_t *)malloc(nctx * A * 4);
+    if (!lvl || !keep) { free(lvl); free(keep); return kmax; }
+    memcpy(lvl, cnt, nctx * A * 4);
+    uint16_t f[256];
+    for (uint32_t k = kmax;; k--) {
+        uint64_t bits = 0, used = 0;
+        for (uint64_t c = 0; c < nctx; c++) {
+            uint64_t T = 0;
+            for (uint32_t s = 0; s < A; s++) T += lvl[c * A + s];
+            if (!T) continue;
+            used++;
+            normalise(lvl + c * A, A, f);
+            for (uint32_t s = 0; s < A; s++) bits += (uint64_t)lvl[c * A + s] * bit_cost(f[s]);
+        }
+        bits = bits / 256 * S + used * A * 16 + nctx;
+        if (bits < bestBits) { bestBits = bits; best = k; memcpy(keep, lvl, nctx * A * 4); }
+        if (k == 0) break;
+        const uint64_t low = nctx / A;                   /* contexts of order k - 1: the k - 1 most recent symbols */
+        for (uint64_t c = low; c < nctx; c++)
+            for (uint32_t s = 0; s < A; s++) {
+                const uint64_t v = (uint64_t)lvl[(c % low) * A + s] + lvl[c * A + s];
+                lvl[(c % low) * A + s] = v > 0xFFFFFFFFu ? 0xFFFFFFFFu : (uint32_t)v;
+            }
+        nctx = low;
+    }
+    uint64_t nb = 1;
+    for (uint32_t j = 0; j < best; j++) nb *= A;
+    memcpy(cnt, keep, nb * A * 4);
+    free(lvl); free(keep);
+    return best;
+}
+
 /* returns the container's length, -1 when `cap` is too small, -2 on allocation failure */
 static int64_t rans_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t cap)
 {
@@ -163,10 +222,10 @@ static int64_t rans_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t
     for (uint32_t b = 0; b < 256; b++) if (present[b]) { map[b] = A; alphabet[A++] = (uint8_t)b; }
     if (A == 0) A = 1;                                  /* empty input: one dummy symbol */
     const uint32_t S = sample_step(n);
-    const uint32_t k = choose_k(A, n / S);
+    uint32_t k = choose_k(A, n / S);                    /* the highest order considered: the counts are taken there */
     uint64_t nctx = 1;
     for (uint32_t j = 0; j < k; j++) nctx *= A;
-    const uint64_t top = nctx;                          /* A^k: weight of the symbol that leaves the context */
+    uint64_t top = nctx;                          /* A^k: weight of the symbol that leaves the context */
     const uint32_t BQC_SEG = choose_seg(n);
     const uint32_t nseg = (uint32_t)((n + BQC_SEG - 1) / BQC_SEG);
     uint32_t *cnt = (uint32_t *)calloc(nctx * A, 4);
@@ -183,6 +242,10 @@ static int64_t rans_encode(const uint8_t *in, uint64_t n, uint8_t *out, uint64_t
             ctx = k ? ctx * A + s - (uint64_t)outgoing * top : 0;
         }
     }
+    k = choose_order(cnt, A, k, S);
+    nctx = 1;
+    for (uint32_t j = 0; j < k; j++) nctx *= A;
+    top = nctx;
     uint64_t nused = 0;
     uint32_t cnt0[256] = {0};
     uint16_t dflt[256] = {0};

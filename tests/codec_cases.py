@@ -37,7 +37,7 @@ def cases():
     out["reads_n_runs"] = reads(rng, 4000, 25, 150, n_runs=True)
     out["reads_low_coverage"] = reads(rng, 4000000, 1, 100)                      # nothing to learn: the static container is smaller and is kept
     long_line = rng.choice(np.frombuffer(b"ACGT", np.uint8), 65535)
-    out["reads_line_65535"] = np.concatenate([reads(rng, 3000, 10, 100), long_line, np.array([10], np.uint8), reads(rng, 3000, 10, 100)])
+    out["reads_line_65535"] = np.concatenate([reads(rng, 3000, 40, 100), long_line, np.array([10], np.uint8), reads(rng, 3000, 40, 100)])
     out["reads_line_65536"] = np.concatenate([reads(rng, 3000, 10, 100), long_line, np.array([65, 10], np.uint8)])
     # headers
     out["headers"] = np.frombuffer(b"".join(b"@SYN.%d\n" % i for i in range(30000)), np.uint8).copy()

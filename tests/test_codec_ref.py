@@ -10,26 +10,26 @@ from tests.codec_cases import cases, sampled_case
 
 PINNED = {
     "constant": (1089, "93ac54242ad00ddffd026b4d461aaf8d"),
-    "dna_like": (99876, "f9736c3a0ebb8fb138ed955047e32f14"),
+    "dna_like": (85710, "8908436e794a063d21d29ff841ba85c5"),
     "empty": (303, "2ff219f3724e3a348c2f26ce6113ec0b"),
     "headers": (21414, "805f6a3ac5b733d6bf3ed344f6631c7e"),
     "one_byte": (313, "2905befabdb22bfbf521f622c0d919b3"),
-    "period4": (1444, "a95d8384fc56cc26b581983201712529"),
+    "period4": (1294, "cccae62e066d6fa97bb415f3314ad7de"),
     "random_bytes": (51862, "32abd53a601caad662bde30ac9e35ea7"),
-    "runs_20_symbols": (69625, "e7b21da3a85beb627d8e585d19fab6ff"),
-    "reads_30x": (52312, "68b0618c5263138740d1aafcb4739342"),
-    "reads_below_64k": (18194, "6013d67bbb0a09805cb47dcfc81cadaa"),
-    "reads_line_65535": (34628, "f67eb72b63841215bb996fb53d754b0f"),
-    "reads_line_65536": (27158, "a9fc6fa57bb6cb85d8202f5b30526ed6"),
-    "reads_low_coverage": (1127146, "dd115392b9f9b7e48bafb1f70d9ea4a8"),
-    "reads_n_runs": (10754, "7347a2d68ffd6d69fbd36f2ad178861d"),
-    "reads_short_lines": (52158, "8d2898ee9965e2d728225b1f171a5e7f"),
+    "runs_20_symbols": (54243, "7536cee1630653bfaff7ec6406863958"),
+    "reads_30x": (52261, "3d504c44d3c9863a41b4f05c8af63b00"),
+    "reads_below_64k": (16433, "b8ea7c3998fc519d3b9c8adadcb83b18"),
+    "reads_line_65535": (51383, "9a723ff6f6b4f7123749bb7a7773c153"),
+    "reads_line_65536": (25315, "062933d188e2438faade821ed829737d"),
+    "reads_low_coverage": (1074049, "fce77501c8f0e2f8cba4d4fc8949629c"),
+    "reads_n_runs": (10703, "692839123ec4f9ee9278599e3c7b66f6"),
+    "reads_short_lines": (41979, "732781ecf67bbe82ab8bd6699ac107b4"),
     "reads_var_len": (19100, "e66711b21d0392e044e572a830420284"),
-    "seg_exact": (9342, "3faa94554ed0c1bc77d6584a80c7135b"),
-    "seg_minus_1": (9342, "7eec4f6ce3e2e6a6e50e4fcec05c1218"),
-    "seg_plus_1": (9342, "836ef8819a3ea51f2810f50368c1ddd8"),
-    "smoothed_qs_like": (165369, "49edd1e008781a06eb21d78173f04a30"),
-    "two_symbols": (10604, "292517ce9c17c424380e120031cc34df"),
+    "seg_exact": (6049, "1bd13eb6b4cf059eba4e312708485bbf"),
+    "seg_minus_1": (6047, "9cf61b80f288462b74feac5f7383c40d"),
+    "seg_plus_1": (6055, "4ee892eeabdab26f610a16cce132ec25"),
+    "smoothed_qs_like": (145220, "84d5696f061dd2649555f4469c95fae0"),
+    "two_symbols": (9581, "7883b1cea8d1738db45801b133237b43"),
 }
 
 
