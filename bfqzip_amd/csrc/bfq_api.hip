@@ -15,6 +15,8 @@
 #include <algorithm>
 #include <new>
 #include "bfq_internal.h"
+#include <atomic>
+extern std::atomic<bool> g_bfqHipStarted;                     // bfq_host.cpp
 #include "bfq_synth.h"
 #include "bfq_device.h"
 #include "bfq_rank.h"
@@ -270,6 +272,7 @@ extern "C" bfq_ctx *bfq_create(int device, const bfq_params *p)
         HIP_CHECK(hipMalloc((void **)&c->d_cnt, sizeof(DevCounters)));
         memset(c->profMs, 0, sizeof c->profMs); memset(c->profLaunches, 0, sizeof c->profLaunches);
         memset(c->profBytes, 0, sizeof c->profBytes);
+        g_bfqHipStarted = true;                                    // (bfq_host.cpp: the output files' populate helpers may map pages now)
         // tables for M=1, computed with the host libm the reference itself would use
         double pw[256];
         for (int q = 0; q < 256; q++) pw[q] = pow(10, -((double)(signed char)q - 33) / 10);

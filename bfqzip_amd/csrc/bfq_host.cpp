@@ -298,6 +298,7 @@ struct bfq_outmap {
     std::atomic<uint64_t> done{0};
     uint64_t nslices = 0;
     std::atomic<bool> noFallocate{false};
+    bool holdForHip = false;                                     // opened before the process had a context: see prefault_worker
     std::atomic<uint64_t> fallocDone{0};                         // bytes from the start of the file whose pages exist
     std::atomic<bool> fallocRunning{false};
     std::thread fallocThread;
@@ -355,8 +356,11 @@ static void populate_slice(bfq_outmap *m, uint64_t idx)
     m->done += e - b;
 }
 // allocates (and zeroes) the file's pages from the front, 128 MiB per call
+extern std::atomic<bool> g_bfqHipStarted;
+static void hold_for_hip(bfq_outmap *m);
 static void falloc_worker(bfq_outmap *m)
 {
+    hold_for_hip(m);
     const uint64_t STEP = 128ull << 20;
     for (uint64_t b = 0;;) {
         if (m->stop.load(std::memory_order_relaxed) || m->failed.load()) break;
@@ -375,8 +379,20 @@ static void falloc_worker(bfq_outmap *m)
     }
     m->fallocRunning = false;
 }
+// MADV_POPULATE_WRITE holds the address space's lock for reading while it maps pages; the HIP runtime's start is thousands of
+// mmap / ioctl calls that take it for writing: with the populate helpers of two output files running, hipGetDeviceCount took
+// 1.0 s instead of 0.15.  The helpers that map pages therefore wait until a context exists (bfq_create says so) -- the
+// thread that allocates the pages (fallocate: the file, not the address space) starts at once.  At most 3 s: a caller that
+// never creates a context still gets its pages.
+std::atomic<bool> g_bfqHipStarted{false};
+static void hold_for_hip(bfq_outmap *m)
+{
+    if (m->holdForHip)
+        for (double t0 = now_s(); !g_bfqHipStarted.load(std::memory_order_relaxed) && !m->stop.load(std::memory_order_relaxed) && now_s() - t0 < 3.0;) usleep(1000);
+}
 static void prefault_worker(bfq_outmap *m)
 {
+    hold_for_hip(m);
     for (;;) {
         if (m->stop.load(std::memory_order_relaxed)) break;
         const uint64_t idx = m->next.fetch_add(1);
@@ -434,6 +450,7 @@ bfq_outmap *bfq_outmap_open(int fd, uint64_t map_len, uint64_t prefault_len)
     if (pe0 < (64ull << 20)) T = 0;                              // small outputs: not worth a thread
     m->alive = T;
     m->tOpen = now_s();
+    m->holdForHip = !g_bfqHipStarted.load();
     if (T) { m->fallocRunning = true; m->fallocThread = std::thread(falloc_worker, m); }
     for (int t = 0; t < T; t++) m->th.emplace_back(prefault_worker, m);
     return m;
