@@ -415,6 +415,8 @@ def dropin_parity(d, N, L, dna, qs):
 
 def device_state(local):
     """Clocks / power cap of the GPU as rocm-smi reports them (why one box runs a pass in 27 ms and another in 33)."""
+    if any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "ROCPROFILER_REGISTER_FORCE_LOAD")) or os.environ.get("ROCPROF_OUTPUT_PATH"):
+        return {"skipped": "under rocprofv3 (rocm-smi is a script: an exec from a process whose GPU the profiler has initialised)"}
     try:
         o = subprocess.run(["rocm-smi", "-d", str(local), "--showclocks", "--showpower", "--showmaxpower", "--showperflevel", "--json"],
                            stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=30, text=True).stdout

@@ -248,6 +248,31 @@ def test_read_order_dna_container(engine):
     engine.set_params()
 
 
+def test_random_read_streams(engine):
+    """Random read-shaped streams (genome size, coverage, read length, fixed / variable lengths with empty lines, error and N
+    rates, N runs) around and above the 64 KiB threshold: whichever container the CPU statement chooses (BFQDNAC1, or the
+    static one when the stream is short / barely covered / has short lines), the GPU produces the same bytes and decodes them."""
+    from tests.codec_cases import reads
+    rng = np.random.default_rng(4242)
+    kinds = {}
+    for it in range(36):
+        G = int(rng.choice([800, 3000, 20000, 100000, 600000]))
+        L = int(rng.choice([20, 36, 76, 100, 151, 250]))
+        cov = int(rng.choice([1, 3, 10, 30, 60]))
+        while G * cov > 2_500_000:
+            cov = max(1, cov // 2)
+        data = reads(rng, G, cov, L, var=bool(rng.integers(0, 2)), n_runs=bool(rng.integers(0, 2)),
+                     err=float(rng.choice([0.0, 0.003, 0.01, 0.05])), n_rate=float(rng.choice([0.0, 0.001, 0.02])))
+        if not len(data):
+            continue
+        blob = np.asarray(engine.stream_compress(data))
+        want = orc.codec_encode(data)
+        assert len(blob) == len(want) and (blob == want).all(), (it, G, L, cov, len(data))
+        assert (np.asarray(engine.stream_decompress(blob)) == data).all(), (it, G, L, cov)
+        kinds[blob[:8].tobytes()] = kinds.get(blob[:8].tobytes(), 0) + 1
+    assert kinds.get(b"BFQDNAC1", 0) >= 8 and kinds.get(b"BFQRANS2", 0) >= 4, kinds
+
+
 def test_bsc_front_end(tmp_path):
     """`external/libbsc/bsc e F F.bsc -T` as BFQzip.py:265-275 runs it, and `bsc d` back."""
     exe = os.path.join(ROOT, "dropin", "external", "libbsc", "bsc")
