@@ -515,12 +515,24 @@ void bfq_step1_device(bfq_ctx *c, const u8 *d_bases, const u8 *d_quals, const u6
     if (!abSwap) { B.w0 = c->alloc<u32>(n + 16); B.w12 = c->alloc<u64>(n + 16); }
     }
     if (bfq_env().trace) fprintf(stderr, "[bfq] sort buffers: A.w12 %p A.w0 %p B.w0 %p B.w12 %p (arena %p)\n", (void *)A.w12, (void *)A.w0, (void *)B.w0, (void *)B.w12, (void *)c->ws);
-    u8 *T8 = (u8 *)A.w0, *Q8 = (u8 *)A.w12;             // dead before the sort's first scatter
+    // k_build_keys writes the records to B, the byte text lying in A (dead before the sort's first scatter writes there).
+    // BFQ_KEY_FUSION=1 (tried in round 3, slower): the records never exist unsorted -- the first pass of the sort makes them
+    // from the text on its way (k_radix_scatter<2>; the byte text then lies in B, which that pass does not touch).  It saves
+    // 12 B/row written + 9.6 B/row read, but the key of a suffix (window, terminator mask, 40-bit packing) costs the scatter
+    // kernel more than the traffic it saves: k_build_keys 17.3 -> 6.4 ms (counts only), pass 0 36.4 -> 66.1 ms, step +17 ms.
+    const bool fused = c->env.keyFusion;
+    u8 *T8 = fused ? (u8 *)B.w0 : (u8 *)A.w0, *Q8 = fused ? (u8 *)B.w12 : (u8 *)A.w12;
     bfq_build_text(c, d_bases, d_quals, d_roff, N, n, T8, Q8, text3, nwords);
     u32 *hist0 = c->alloc<u32>(256 * ceil_div(n, bfq_radix_block_elems(n)));
-    bfq_build_keys(c, T8, Q8, text3, n, B, hist0);      // the records start in B: five passes later they are in A
     static_assert(BFQ_KEY_PASSES & 1, "an odd number of passes ends in the other buffer");
-    bfq_radix_sort(c, B, A, n, BFQ_KEY_PASSES, hist0);
+    if (fused) {
+        bfq_key_hist(c, text3, n, hist0);               // the first pass's digit counts
+        const RadixText tx{T8, Q8, text3};
+        bfq_radix_sort(c, B, A, n, BFQ_KEY_PASSES, hist0, &tx);   // text -> A -> B -> A -> B -> A
+    } else {
+        bfq_build_keys(c, T8, Q8, text3, n, B, hist0);
+        bfq_radix_sort(c, B, A, n, BFQ_KEY_PASSES, hist0);
+    }
     c->release(mB);                                     // the big-segment list reuses the B buffers
     bfq_refine(c, A, text3, n, c->d_lcp, st);
     bfq_emit_bwt(c, A, n, termOut, c->d_bwt, c->d_qual, c->d_gcnt);

@@ -72,6 +72,7 @@ BfqEnv bfq_env_read()
         e.compactWin = getu("BFQ_COMPACT_WIN", 0);
         e.compactRing = getu("BFQ_COMPACT_RING", 0);
         e.dnaStatic = geti("BFQ_DNA_STATIC", 0);
+        e.keyFusion = geti("BFQ_KEY_FUSION", 0) != 0;
         e.dnacK = geti("BFQ_DNAC_K", 0); e.dnacH = geti("BFQ_DNAC_H", 0); e.dnacW = geti("BFQ_DNAC_W", 0); e.dnacSkip = geti("BFQ_DNAC_TSKIP", -1);
         e.wsVmmMib = geti("BFQ_WS_VMM", 0);
         e.rsPerm = geti("BFQ_RS_PERM", 0) != 0;

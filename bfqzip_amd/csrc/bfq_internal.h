@@ -232,7 +232,9 @@ static inline u64 bfq_radix_block_elems(u64 n)
 }
 void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u64 n, SortRec out, u32 *hist0);   // hist0: [256][ceil(n / bfq_radix_block_elems(n))]
 // LSD radix sort of the records on their 48-bit key; result ends in A
-SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes = BFQ_KEY_PASSES, const u32 *hist0 = nullptr);   // returns the buffer holding the result (in: even passes, tmp: odd); fewer passes = low digits only; hist0: pass-0 counts already made
+struct RadixText { const u8 *T8, *Q8; const u64 *text3; };   // the terminated text the first pass makes its records from
+void bfq_key_hist(bfq_ctx *c, const u64 *text3, u64 n, u32 *hist0);                                   // k_text.hip
+SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes = BFQ_KEY_PASSES, const u32 *hist0 = nullptr, const RadixText *fromText = nullptr);   // returns the buffer holding the result (in: even passes, tmp: odd); fewer passes = low digits only; hist0: pass-0 counts already made
 // tie refinement: sorts vals inside equal-key segments by the remaining suffix, fills lcp
 void bfq_refine(bfq_ctx *c, SortRec rec, const u64 *text3, u64 n, u16 *lcp, bfq_stats *st);
 // segments above BFQ_HUGE_SEG rows (listed by k_refine_big): whole-device radix rounds on the following symbols

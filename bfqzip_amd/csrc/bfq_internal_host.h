@@ -29,6 +29,7 @@ struct BfqEnv {
     char abOrder[8] = {0};          // BFQ_AB_ORDER=<permutation of 0123>: the order of A.w12, A.w0, B.w0, B.w12 in the arena (placement experiments)
     bool abSwap = false;            // BFQ_AB_SWAP=1: the second record buffer below the first (placement experiments)
     bool compact = false;           // BFQ_COMPACT=1: steps 2-4 on a given eBWT + LCP without the LF table whatever the cap (k_compact.hip; test knob)
+    bool keyFusion = false;         // BFQ_KEY_FUSION=1: the sort's records are made by its first scatter pass from the text (slower: bfq_api.hip)
     int dnaStatic = 0;              // BFQ_DNA_STATIC=1: read-order DNA through the static BFQRANS2 container as well (4x faster, 3x larger)
     int dnacK = 0, dnacH = 0, dnacW = 0, dnacSkip = -1;   // BFQ_DNAC_K / _H / _W / _TSKIP: the BFQDNAC1 container's parameters (the header carries them; defaults in k_dnac.hip)
     unsigned long long compactRing = 0; // BFQ_COMPACT_RING: entries of the interval refinement's ring queue there (default: what the cap leaves; small values test the chunked levels / the move to host memory)

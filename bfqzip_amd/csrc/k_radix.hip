@@ -60,10 +60,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const T *__restrict__
     }
 }
 
-// DW = which word carries the digit of this pass (0: w0, 1: w1)
+// DW = which word carries the digit of this pass (0: w0, 1: w1); 2: w1, and the records do not exist yet -- record i is made
+// here from the text (suffix i: its 16-symbol key, position, preceding symbol and quality, exactly what k_build_keys
+// would have written): the sort's first pass then reads 2.4 bytes per row instead of 12, and nobody writes those 12.
 template <int DW>
 __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in, SortRec out, u64 n, int shift,
-                                                              const u64 *__restrict__ blockOff, u64 nblocks, u32 tilesPerBlock, u64 blockMul)
+                                                              const u64 *__restrict__ blockOff, u64 nblocks, u32 tilesPerBlock, u64 blockMul,
+                                                              RadixText tx)
 {
     __shared__ u64 stage[RS_TILE];          // w0, then the (w1,w2) pair of the records
     __shared__ u8 dig[RS_TILE];             // digit of every tile-sorted slot
@@ -99,10 +102,23 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
         for (int r = 0; r < RS_ROUNDS; r++) {
             const u32 slot = w * (RS_ROUNDS * 64) + r * 64 + lane;
             const u64 src = tbase + (slot < lastSlot ? slot : lastSlot);
-            a0[r] = in.w0[src];
-            const u64 x12 = in.w12[src];
-            a1[r] = (u32)x12;
-            a2[r] = (u32)(x12 >> 32);
+            if (DW == 2) {
+                const u64 wd = src / BFQ_SYMS_PER_WORD;
+                const u32 o3 = (u32)(src - wd * BFQ_SYMS_PER_WORD) * 3u;
+                const u64 *t3 = tx.text3 + bfq_t3_at(wd);
+                const u64 hi = (t3[0] << o3) & BFQ_M63;
+                const u64 lo = o3 ? (t3[1] >> (63u - o3)) : 0ull;
+                const u64 sk = bfq_skey_of(bfq_mask_key(hi | lo));
+                const u32 pc = src ? (u32)tx.T8[src - 1] : 0u;
+                const u32 pq = pc ? (u32)tx.Q8[src - 1] : (u32)'#';
+                const u64 pay = bfq_pack_val(src, pc, pq);
+                a0[r] = bfq_rec_w0(sk); a1[r] = bfq_rec_w1(sk, pay); a2[r] = bfq_rec_w2(pay);
+            } else {
+                a0[r] = in.w0[src];
+                const u64 x12 = in.w12[src];
+                a1[r] = (u32)x12;
+                a2[r] = (u32)(x12 >> 32);
+            }
         }
 #pragma unroll
         for (int r = 0; r < RS_ROUNDS; r++) {
@@ -179,7 +195,7 @@ __global__ __launch_bounds__(RS_THREADS, RS_OCC) void k_radix_scatter(SortRec in
 
 // skey digits: 0 in w1 (bits 24..31), 1..4 in w0.  The records start in `in`; `tmp` is the other ping-pong buffer.
 // Returns the buffer that holds the result: `in` for an even number of passes, `tmp` for an odd one.
-SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes, const u32 *hist0)
+SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes, const u32 *hist0, const RadixText *fromText)
 {
     if (n < 2) {
         if (n == 1 && (passes & 1)) {
@@ -211,10 +227,13 @@ SortRec bfq_radix_sort(bfq_ctx *c, SortRec in, SortRec tmp, u64 n, int passes, c
         else if (!have)
             KLAUNCH(c, K_RADIX_HIST, 4.0 * (double)n, k_radix_hist<u32>, nb, RS_THREADS, (const u32 *)in.w0, n, shift, hist, nb, be);
         bfq_exscan_u32(c, have ? hist0 : hist, off, 256 * nb, nullptr);
-        if (dw)
-            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb, mul);
+        const RadixText none{nullptr, nullptr, nullptr};
+        if (dw && fromText && have)                        // the records are made on the way: 12 B written + 2.4 B of text read per row
+            KLAUNCH(c, K_RADIX_SCATTER, 14.4 * (double)n, k_radix_scatter<2>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb, mul, *fromText);
+        else if (dw)
+            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<1>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb, mul, none);
         else
-            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<0>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb, mul);
+            KLAUNCH(c, K_RADIX_SCATTER, 24.0 * (double)n, k_radix_scatter<0>, nb, RS_THREADS, in, out, n, shift, (const u64 *)off, nb, tpb, mul, none);
         SortRec t = in; in = out; out = t;
     }
     c->release(m);

@@ -87,6 +87,9 @@ __global__ __launch_bounds__(256) void k_pack3(const u8 *__restrict__ T8, u64 n,
 // 4 consecutive suffixes per thread: 16-symbol key + payload (position, previous symbol, its quality) as
 // 12-byte records; the previous symbols / qualities arrive by one 4-byte load each, the records leave as
 // one 16-byte (w0) and two 16-byte (w12) stores
+// STORE = false: only the digit counts (the sort's first scatter builds the records itself, straight from the text:
+// k_radix_scatter<2>) -- no T8 / Q8 reads, no record stores.
+template <bool STORE>
 __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, const u8 *__restrict__ Q8,
                                                     const u64 *__restrict__ text3, u64 n, SortRec out, u32 *__restrict__ hist0,
                                                     u64 nblocks, u64 blockElems)
@@ -108,8 +111,10 @@ __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, c
         u32 o0 = (u32)(p0 - w0 * BFQ_SYMS_PER_WORD);
         for (; p0 < bend; p0 += 1024) {
             u32 c4 = 0, q4 = 0;                                       // codes / qualities of text positions p0-1 .. p0+2
-            if (p0 >= 1 && p0 + 3 <= n) { c4 = *(const u32 *)(T8 + p0 - 1); q4 = *(const u32 *)(Q8 + p0 - 1); }
-            else for (int k = 0; k < 4; k++) { u64 t = p0 + k; if (t >= 1 && t - 1 < n) { c4 |= (u32)T8[t - 1] << (8 * k); q4 |= (u32)Q8[t - 1] << (8 * k); } }
+            if (STORE) {
+                if (p0 >= 1 && p0 + 3 <= n) { c4 = *(const u32 *)(T8 + p0 - 1); q4 = *(const u32 *)(Q8 + p0 - 1); }
+                else for (int k = 0; k < 4; k++) { u64 t = p0 + k; if (t >= 1 && t - 1 < n) { c4 |= (u32)T8[t - 1] << (8 * k); q4 |= (u32)Q8[t - 1] << (8 * k); } }
+            }
             const u64 *t3 = text3 + bfq_t3_at(w0);
             u64 t0 = t3[0], t1 = t3[1], t2 = t3[2];                   // 4 windows span at most 3 words
             u32 rw0[4];
@@ -131,7 +136,8 @@ __global__ __launch_bounds__(256) void k_build_keys(const u8 *__restrict__ T8, c
                 if (p0 + k < n) atomicAdd(&wh[w][(u32)sk & 255u], 1u);   // digit 0 of the LSD sort = low byte of the key
                 if (++o == BFQ_SYMS_PER_WORD) { o = 0; wd++; }
             }
-            if (p0 + 4 <= n) {
+            if (!STORE) { }
+            else if (p0 + 4 <= n) {
                 *(uint4 *)(out.w0 + p0) = make_uint4(rw0[0], rw0[1], rw0[2], rw0[3]);
                 *(ulonglong2 *)(out.w12 + p0) = make_ulonglong2(rw12[0], rw12[1]);
                 *(ulonglong2 *)(out.w12 + p0 + 2) = make_ulonglong2(rw12[2], rw12[3]);
@@ -170,5 +176,13 @@ void bfq_build_keys(bfq_ctx *c, const u8 *T8, const u8 *Q8, const u64 *text3, u6
     if (!n) return;
     const u64 be = bfq_radix_block_elems(n);
     const u64 nb = ceil_div(n, be);
-    KLAUNCH(c, K_KEYS, 14.5 * (double)n, k_build_keys, bfq_grid(nb, 1), 256, T8, Q8, text3, n, out, hist0, nb, be);
+    KLAUNCH(c, K_KEYS, 14.5 * (double)n, k_build_keys<true>, bfq_grid(nb, 1), 256, T8, Q8, text3, n, out, hist0, nb, be);
+}
+// only the first pass's digit counts (the records are made by that pass itself: bfq_radix_sort(.., fromText))
+void bfq_key_hist(bfq_ctx *c, const u64 *text3, u64 n, u32 *hist0)
+{
+    if (!n) return;
+    const u64 be = bfq_radix_block_elems(n);
+    const u64 nb = ceil_div(n, be);
+    KLAUNCH(c, K_KEYS, 0.4 * (double)n, k_build_keys<false>, bfq_grid(nb, 1), 256, (const u8 *)nullptr, (const u8 *)nullptr, text3, n, SortRec{nullptr, nullptr}, hist0, nb, be);
 }
