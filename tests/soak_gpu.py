@@ -12,8 +12,9 @@ identical suffixes shuffled, the FASTQ job (text in, FASTQ text + streams out) a
 Since the stream codec exists every case also checks step 5 (containers = CPU statement, eBWT-domain containers back to the streams).
 Round 2 totals: 31 992 cases / 8.4 G rows in fifteen runs (the last ten with the 40-bit sort key, the last three with the
 step-5 checks, one of those pile by pile), all bit-exact.
-Round 3 adds per case: the capped mode (bfq_params.piles = 2: run_reads and the FASTQ job) and the global mode's streams
-(written through the mapped output files)."""
+Round 3 adds per case: the capped mode (bfq_params.piles = 2: run_reads and the FASTQ job), the global mode's streams
+(written through the mapped output files), steps 2-4 without the LF table (k_compact.hip: both jobs, random ring / window
+sizes) and, through the step-5 check, the read-order DNA container (BFQDNAC1) on every stream of 64 KiB and more."""
 import sys, time, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -98,6 +99,22 @@ def run_case(eng, O, seed):
     if len(bwt):
         sb, sq, sroff, sst = eng.smooth_invert(bwt, qs)
         ok = ok and np.array_equal(sb, ob) and np.array_equal(sq, oq) and np.array_equal(sroff, r)
+        # round 3: the same two jobs without the LF table (k_compact.hip: what runs under a workspace cap) -- bfq_int's with
+        # a ring queue of a random size (levels in chunks / the queue moved to host memory), bfq_ext's with a random LCP window
+        os.environ["BFQ_COMPACT"] = "1"
+        os.environ["BFQ_COMPACT_RING"] = str(int(rng.choice([64, 300, 5000, 1 << 20])))
+        os.environ["BFQ_COMPACT_WIN"] = str(int(rng.choice([100, 5000, 1 << 22])))
+        try:
+            eng.set_params(piles=piles, **par)                    # (the environment is read when parameters are set)
+            cb, cq, croff, cst = eng.smooth_invert(bwt, qs)
+            ok = ok and np.array_equal(cb, ob) and np.array_equal(cq, oq) and np.array_equal(croff, r) and all(sst[k] == cst[k] for k in sst)
+            if int(lcp.max(initial=0)) < 65536:
+                xb, xq, xroff, xst = eng.smooth_invert(bwt, qs, lcp.astype(np.uint16 if rng.integers(0, 2) else np.uint32))
+                ok = ok and np.array_equal(xb, ob) and np.array_equal(xq, oq) and np.array_equal(xroff, r) and all(sst[k] == xst[k] for k in sst)
+        finally:
+            for k in ("BFQ_COMPACT", "BFQ_COMPACT_RING", "BFQ_COMPACT_WIN"):
+                del os.environ[k]
+            eng.set_params(piles=piles, **par)
     if 0 < len(bwt) <= 4000:                                  # any tie order: the reference sees one terminator symbol
         tb, tq = util.shuffle_ties(bwt, qs, rng)
         eb, eq, eroff, est = O.smooth_invert(tb, tq, None, p)
