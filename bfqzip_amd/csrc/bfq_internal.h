@@ -72,7 +72,7 @@ struct bfq_ctx {
 
     // workspace arena (bump allocator, reset per top-level call)
     char *ws = nullptr;
-    size_t wsCap = 0, wsTop = 0;
+    size_t wsCap = 0, wsTop = 0, wsPeak = 0;
     void reserve(size_t bytes);
     void wsFree();
     // an arena being allocated on a helper thread while the caller uploads its input (a one-shot tool's 86 GB can land on
