@@ -54,7 +54,9 @@ typedef struct bfq_params {
                        ~8 n: two-symbol piles one at a time, edits written to the text position of every row, no eBWT-sized
                        array, no LF table, no inversion -- same bytes out, about a third more time.  Steps 2-4
                        on a GIVEN eBWT (bfq_smooth_invert*: 17 n with the LF table) then run on 64-byte rank blocks answered
-                       on demand, qualities edited in place and a replacement array: 7 n (LCP given) / 9 n (deduced)          */
+                       on demand, qualities edited in place and a replacement array: 7.3 n (LCP given) / 7.8 n + the ring
+                       queue of the LCP deduction (deduced: the ring takes what the cap leaves, n/16 entries at least), the
+                       eBWT and the qualities themselves included in the count                                            */
     int32_t reserved[5];
 } bfq_params;
 
