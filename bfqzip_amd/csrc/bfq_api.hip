@@ -1164,11 +1164,12 @@ static void fastq_build_ebwt_oneshot(bfq_ctx *c, int fastq_fd, uint64_t len, int
     // allocations wait for it (profiles/microbench/alloc_after_exit.hip; profiles/r3/dropin_phases.md: bfq_int waited 1.3-4.3 s
     // behind a gsufsort that had held 102 GiB).  So every piece is as small as its contents and goes back the moment it is dead:
     //   text buffer   the FASTQ text, then (the reads gathered) the eBWT and its qualities until they are written
-    //   parse arena   line index, records, gathered reads: freed once the terminated text is built
+    //   parse arena   line index, records, gathered reads: dead once the terminated text is built -- and then
+    //   arena         sort records + histograms of ONE pile, sized from the actual pile sizes, in the parse arena's memory
+    //                 (what the next process waits for is everything this one ever gave back, not what it held last)
     //   text arrays   T8 / Q8 / packed text: until the last pile is sorted
-    //   arena         sort records + histograms of ONE pile, sized from the actual pile sizes
     char *pws = nullptr, *tws = nullptr;
-    char *const ws0 = c->ws; const size_t cap0 = c->wsCap;
+    char *ws0 = c->ws; size_t cap0 = c->wsCap;
     bool swapped = false;
     auto restoreArena = [&] { if (swapped) { c->ws = ws0; c->wsCap = cap0; c->wsTop = 0; swapped = false; } };
     auto finish = [&](bool ok) {
@@ -1197,7 +1198,8 @@ static void fastq_build_ebwt_oneshot(bfq_ctx *c, int fastq_fd, uint64_t len, int
         bfq_phase("alloc");
         const size_t parseBytes = (tl + 8192) + 128 * (Nb + 64) + 8 * (nlines + 64) + 16 * (tl / 4096 + 16) + (64u << 20);
         if (hipMalloc((void **)&pws, parseBytes) != hipSuccess) { (void)hipGetLastError(); pws = nullptr; throw BfqError{BFQ_E_NOMEM, "device buffer for the parsed records"}; }
-        c->ws = pws; c->wsCap = parseBytes; c->wsTop = 0; swapped = true;      // ws0 (the small arena) comes back below
+        ws0 = c->ws; cap0 = c->wsCap;                                          // (the small arena of the line count)
+        c->ws = pws; c->wsCap = parseBytes; c->wsTop = 0; swapped = true;      // ws0 comes back below
         bfq_phase("gpu");
         c->zeroCounters();
         DevFastq fq;
@@ -1249,8 +1251,7 @@ static void fastq_build_ebwt_oneshot(bfq_ctx *c, int fastq_fd, uint64_t len, int
             bfq_pile_pair_counts(c, pt.T8, n, cnt);             // synchronises
             c->fetchCounters();
             check_counters(c);                                  // forbidden symbols, reads beyond BFQ_MAX_READ_LEN
-            restoreArena();
-            (void)hipFree(pws); pws = nullptr;                  // the parsed reads are dead
+            restoreArena();                                     // the parsed reads are dead
             // piles above an eighth of the rows are split by their second symbol; the arena holds the largest piece
             const u64 capTarget = n / 8 + (1u << 20);
             u64 cap = 1u << 20;
@@ -1260,7 +1261,12 @@ static void fastq_build_ebwt_oneshot(bfq_ctx *c, int fastq_fd, uint64_t len, int
                 cap = std::max(cap, tot <= capTarget ? tot : big);
             }
             bfq_phase("alloc");
-            c->reserve(bfq_ws_need_piles(n, N, cap, lcpExtra + (wantLcp ? 2 * (n + 256) : 0), true));
+            const size_t needPiles = bfq_ws_need_piles(n, N, cap, lcpExtra + (wantLcp ? 2 * (n + 256) : 0), true);
+            if (parseBytes >= needPiles + (1u << 20) && !(c->wsLimit() && parseBytes > c->wsLimit())) {
+                c->wsFree();                                    // the pile arena lives where the parsed reads were
+                c->ws = pws; c->wsCap = parseBytes; c->wsTop = 0; pws = nullptr;
+            } else { (void)hipFree(pws); pws = nullptr; }
+            c->reserve(needPiles);
             bfq_phase("gpu");
             c->piles = true;
             c->lcpScratch = !wantLcp;
