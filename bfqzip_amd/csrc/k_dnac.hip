@@ -346,6 +346,8 @@ struct DqInput { u64 nreads = 0, nbases = 0; u32 *lens = nullptr; u64 *boff = nu
 static bool dq_prepare(bfq_ctx *c, DqMem &M, const u8 *d_in, u64 n, DqInput &I)
 {
     if (n < 65536 || c->env.dnaStatic) return false;
+    // under a workspace cap the context table (8 bytes per base, up to 34 GB) must fit what the arena has left: else the static container
+    if (c->wsLimit() && c->wsCap - c->wsTop < (8ull << dq_H(n)) + 4 * n + (256u << 20)) return false;
     u8 last = 0;
     HIP_CHECK(hipMemcpyAsync(&last, d_in + n - 1, 1, hipMemcpyDeviceToHost, c->stream));
     const u64 nl = bfq_fastq_count_lines(c, d_in, n) - 1;        // (synchronises)
