@@ -275,7 +275,13 @@ def ebwt_modes(api, eng, text, N, L, log):
     dt = time.perf_counter() - t0
     res["build_ebwt"] = {"wall_ms": round(dt * 1e3, 1), "Mbases_per_s": round(N * L / 1e6 / dt, 1)}
     log(f"build_ebwt (gsufsort / eGap boundary): {dt * 1e3:.0f} ms")
-    for name, l in (("bfq_int", None), ("bfq_ext", lcp)):
+    # (bfq_ext as BFQzip_ext.py runs it reads eGap's 1-byte LCP file, `--lbytes 1`: entries clamped at 255 -- the same flags for
+    # reads below 255 bases, half the upload)
+    pin8 = api.PinnedBuffer(n)
+    lcp8 = pin8.array[:n]
+    lcp8[:] = np.minimum(lcp, 255).astype(np.uint8)
+    pins.append(pin8)
+    for name, l in (("bfq_int", None), ("bfq_ext", lcp), ("bfq_ext_lbytes1", lcp8)):
         eng.smooth_invert(bwt, qs, l, out=out)                      # warm-up: sizes the workspace
         eng.prof_reset()
         t0 = time.perf_counter()
@@ -290,7 +296,7 @@ def ebwt_modes(api, eng, text, N, L, log):
         p.free()
     res["what"] = ("build_ebwt: bfq_fastq_build_ebwt, FASTQ text -> eBWT + QS + 2-byte LCP (pinned host arrays); bfq_int / bfq_ext: "
                    "bfq_smooth_invert on those arrays -> host reads: upload, [LCP from the BWT | LCP upload], LF table, clusters, "
-                   "two LF walks (lengths, reads), download")
+                   "two LF walks (lengths, reads), download; bfq_ext_lbytes1: the LCP as eGap's 1-byte file holds it (BFQzip_ext.py:172-177)")
     return res
 
 
